@@ -1,0 +1,134 @@
+/* mmr.h -- C ABI of the MI355X-native CLIP encode + cosine top-k hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: its scripts
+ * call a Python object API (`clip.load(...)` -> model.encode_image / encode_text / model(...),
+ * reference code/test_clip.py:6-16, code/search_image.py:132,156,335) and plain tensor
+ * expressions for scoring/ranking (code/search_image.py:107, code/utils.py:17).  This header is
+ * what a Python shim binds with ctypes to replace that path; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (tensor.data_ptr()) unless named *_host;
+ *   - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - no allocation, no synchronisation inside: the caller owns outputs and workspace, calls
+ *     are asynchronous on `stream` and are hipGraph-capturable;
+ *   - return 0 on success or a negative errno-style code; mmr_last_error() gives the text
+ *     (thread-local).  Arguments are validated on the host BEFORE any launch.
+ */
+#ifndef MMR_H
+#define MMR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { MMR_F32 = 0, MMR_BF16 = 1 } mmr_dtype;
+
+enum {
+    MMR_OK = 0,
+    MMR_EIO = -5,      /* a HIP runtime call failed */
+    MMR_EINVAL = -22,  /* bad argument (shape, dtype, alignment, null pointer) */
+    MMR_ENOSPC = -28,  /* workspace smaller than *_workspace_bytes() */
+    MMR_ENOTSUP = -95  /* shape outside what the kernels are built for */
+};
+
+const char *mmr_last_error(void);
+int mmr_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Similarity / ranking  (replaces reference code/search_image.py:107 `100. * F @ r.t()`,
+ * code/utils.py:17 `output.topk(k,1,True,True)`, code/search_image.py:133,157 `f /= f.norm()`).
+ * ---------------------------------------------------------------------------------------- */
+
+/* Bytes of scratch mmr_cosine_topk needs for this problem size. */
+size_t mmr_search_workspace_bytes(int64_t N, int E, int Q, int k);
+
+/* Top-k gallery rows per query by dot product, ordered by (-dot, +row index).
+ *   q[Q,E], gallery[N,E] row-major, dtype fp32 or bf16 (both operands the same dtype).
+ *   idx[Q,k] int32 row ids (-1 past N), score[Q,k] = (float)(dot64*scale),
+ *   dot64[Q,k] (nullable) the exact fp64 dot products used for ranking,
+ *   status[Q] (nullable): 0 = MFMA scan + certified exact re-rank, 1 = exhaustive exact path.
+ *   scale must be > 0.  gallery_norm_bound: upper bound on the L2 norm of any gallery row
+ *   (1.0 for a normalised gallery); it only sizes the certification margin, never the result.
+ * Ranking is on fp64 dot products accumulated in the fixed order documented in
+ * oracle/search_ref.c, so indices are bit-reproducible against the CPU oracle. */
+int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
+                    float scale, float gallery_norm_bound, int32_t *idx, float *score, double *dot64,
+                    int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
+/* out[Q,N] (fp32) = (float)(dot64 * scale): the materialised score matrix for small N. */
+int mmr_similarity(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, float scale,
+                   float *out, void *stream);
+
+/* In-place row-wise x /= ||x||_2 (no epsilon, like the reference). */
+int mmr_l2norm_rows(void *x, mmr_dtype dtype, int64_t rows, int E, void *stream);
+
+/* Merge `parts` per-shard lists [parts,Q,k] (global int64 ids, fp64 dots; id < 0 = empty slot)
+ * into one [Q,k] list with the same ordering.  Used after the RCCL all-gather. */
+int mmr_topk_merge(const int64_t *idx_parts, const double *dot_parts, int parts, int Q, int k, float scale,
+                   int64_t *idx, float *score, double *dot64, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Encoder towers  (replaces model.encode_image / encode_text of the `clip` package and
+ * CLIPModel.get_image_features of transformers; arithmetic per SURVEY.md Appendix A).
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct {
+    int kind;        /* 0 = vision, 1 = text */
+    int width;       /* d, multiple of 128 */
+    int layers;
+    int heads;       /* width / 64 */
+    int mlp;         /* multiple of 128 */
+    int tokens;      /* vision: 1 + (image_size/patch)^2; text: context length */
+    int embed_dim;   /* E, multiple of 128 */
+    int image_size;  /* vision only */
+    int patch;       /* vision only */
+    int vocab;       /* text only */
+    float ln_eps;
+} mmr_tower_cfg;
+
+/* Tensors of the weight blob.  Matrices are bf16 row-major [out,in]; vectors/embeddings fp32
+ * except TOK_EMB (bf16 [vocab,d]).  PATCH_W is [d, Kpad] with K = (c,ky,kx) order zero-padded
+ * to a multiple of 64.  `layer` is ignored for non-per-layer tensors. */
+typedef enum {
+    MMR_P_PATCH_W = 0, MMR_P_CLS, MMR_P_POS, MMR_P_LN_PRE_W, MMR_P_LN_PRE_B,
+    MMR_P_LN1_W, MMR_P_LN1_B, MMR_P_QKV_W, MMR_P_QKV_B, MMR_P_OUT_W, MMR_P_OUT_B,
+    MMR_P_LN2_W, MMR_P_LN2_B, MMR_P_FC1_W, MMR_P_FC1_B, MMR_P_FC2_W, MMR_P_FC2_B,
+    MMR_P_LN_FINAL_W, MMR_P_LN_FINAL_B, MMR_P_PROJ, MMR_P_TOK_EMB,
+    MMR_P_COUNT
+} mmr_param;
+
+size_t mmr_tower_weights_bytes(const mmr_tower_cfg *cfg);
+/* Byte offset/size of one tensor inside the blob; returns MMR_EINVAL if the tower has no such tensor. */
+int mmr_tower_param_span(const mmr_tower_cfg *cfg, int param, int layer, size_t *offset, size_t *bytes);
+
+typedef struct mmr_tower mmr_tower;
+
+/* `weights` is a device blob laid out per mmr_tower_param_span; it must outlive the tower. */
+int mmr_tower_create(const mmr_tower_cfg *cfg, const void *weights, size_t weights_bytes, mmr_tower **out);
+void mmr_tower_destroy(mmr_tower *t);
+size_t mmr_tower_workspace_bytes(const mmr_tower *t, int batch);
+
+/* pixels[B,3,S,S] NCHW contiguous (fp32 or bf16) -> out[B,E] (fp32 or bf16).
+ * normalize != 0 applies the row L2 normalisation before the store. */
+int mmr_vit_encode_image(mmr_tower *t, const void *pixels, mmr_dtype in_dtype, int B, void *out,
+                         mmr_dtype out_dtype, int normalize, void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* ids[N,T] int32 (EOT = largest id per row) -> out[N,E]. */
+int mmr_text_encode(mmr_tower *t, const int32_t *ids, int N, void *out, mmr_dtype out_dtype, int normalize,
+                    void *workspace, size_t workspace_bytes, void *stream);
+
+/* Same forward with a tap on the fp32 residual stream for stage-level parity tests:
+ * tap_after = -1 copies h after the embedding (+pre-LN for vision); i >= 0 after block i.
+ * tap[B*T, d] fp32 (nullable).  `input` is pixels (vision) or ids (text). */
+int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_dtype, int B, void *out,
+                      mmr_dtype out_dtype, int normalize, int tap_after, float *tap, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMR_H */
