@@ -1,0 +1,101 @@
+"""ctypes binding of csrc/libmmr_hip.so (the C ABI in include/mmr.h).
+
+There is deliberately no fallback: if the HIP library is missing or a call fails, the
+caller gets an exception -- never a silent CPU/torch path.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libmmr_hip.so")
+
+MMR_F32, MMR_BF16 = 0, 1
+_ERRNAMES = {-5: "EIO", -22: "EINVAL", -28: "ENOSPC", -95: "ENOTSUP"}
+
+
+class MMRError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libmmr_hip: {_ERRNAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class TowerCfg(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in
+                ("kind", "width", "layers", "heads", "mlp", "tokens", "embed_dim", "image_size", "patch", "vocab")]
+    _fields_.append(("ln_eps", ctypes.c_float))
+
+
+# parameter ids, mirrored from include/mmr.h (mmr_param)
+(P_PATCH_W, P_CLS, P_POS, P_LN_PRE_W, P_LN_PRE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_OUT_W, P_OUT_B,
+ P_LN2_W, P_LN2_B, P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B, P_LN_FINAL_W, P_LN_FINAL_B, P_PROJ, P_TOK_EMB,
+ P_COUNT) = range(22)
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for this path.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, f32, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+    L.mmr_last_error.restype = ctypes.c_char_p
+    L.mmr_version.restype = i32
+    L.mmr_search_workspace_bytes.restype = sz
+    L.mmr_search_workspace_bytes.argtypes = [i64, i32, i32, i32]
+    L.mmr_cosine_topk.restype = i32
+    L.mmr_cosine_topk.argtypes = [vp, vp, i32, i32, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
+    L.mmr_similarity.restype = i32
+    L.mmr_similarity.argtypes = [vp, vp, i32, i32, i64, i32, f32, vp, vp]
+    L.mmr_l2norm_rows.restype = i32
+    L.mmr_l2norm_rows.argtypes = [vp, i32, i64, i32, vp]
+    L.mmr_topk_merge.restype = i32
+    L.mmr_topk_merge.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
+    if hasattr(L, "mmr_tower_create"):
+        cfgp = ctypes.POINTER(TowerCfg)
+        L.mmr_tower_weights_bytes.restype = sz
+        L.mmr_tower_weights_bytes.argtypes = [cfgp]
+        L.mmr_tower_param_span.restype = i32
+        L.mmr_tower_param_span.argtypes = [cfgp, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
+        L.mmr_tower_create.restype = i32
+        L.mmr_tower_create.argtypes = [cfgp, vp, sz, ctypes.POINTER(vp)]
+        L.mmr_tower_destroy.restype = None
+        L.mmr_tower_destroy.argtypes = [vp]
+        L.mmr_tower_workspace_bytes.restype = sz
+        L.mmr_tower_workspace_bytes.argtypes = [vp, i32]
+        L.mmr_vit_encode_image.restype = i32
+        L.mmr_vit_encode_image.argtypes = [vp, vp, i32, i32, vp, i32, i32, vp, sz, vp]
+        L.mmr_text_encode.restype = i32
+        L.mmr_text_encode.argtypes = [vp, vp, i32, vp, i32, i32, vp, sz, vp]
+        L.mmr_tower_forward.restype = i32
+        L.mmr_tower_forward.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, sz, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise MMRError(rc, lib().mmr_last_error().decode())
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float32:
+        return MMR_F32
+    if dt == torch.bfloat16:
+        return MMR_BF16
+    raise TypeError(f"libmmr_hip handles float32 and bfloat16 tensors, got {dt}")
+
+
+def stream_ptr(device=None) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

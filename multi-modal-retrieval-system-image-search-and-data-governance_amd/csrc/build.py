@@ -1,0 +1,60 @@
+"""Builds csrc/libmmr_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+    python -m mmr_amd.csrc.build        # or: __graft_entry__.build()
+
+The shared library has no torch / python dependency: it links only the HIP runtime and
+exports the C ABI declared in include/mmr.h.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["api_common.cpp", "search.hip", "gemm.hip", "vit_ops.hip", "tower.hip"]
+LIB = os.path.join(HERE, "libmmr_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
+         "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def _obj(src):
+    return os.path.join(HERE, "_obj", os.path.splitext(src)[0] + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(os.path.join(HERE, "_obj"), exist_ok=True)
+    headers = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "..", "include", "mmr.h"))
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(HERE, s))]
+
+    def compile_one(src):
+        sp, op = os.path.join(HERE, src), _obj(src)
+        if force or _stale(op, [sp] + headers):
+            cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", op]
+            if verbose:
+                print("[mmr build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+            return True
+        return False
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        rebuilt = list(ex.map(compile_one, srcs))
+    objs = [_obj(s) for s in srcs]
+    if force or any(rebuilt) or _stale(LIB, objs):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print("[mmr build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,769 @@
+// Cosine / dot-product top-k over a gallery matrix for gfx950 (MI355X).
+//
+// Replaces the reference's scoring + ranking expressions
+//     similarity = 100. * features @ ref_feature.t()     reference code/search_image.py:107
+//     output.topk(k, 1, True, True)                       reference code/utils.py:17
+// generalised to Q query rows.  The [Q,N] score matrix is never
+// written.
+//
+// Structure (DESIGN.md "search"):
+//   scan_kernel      HBM-bound.  Streams the bf16 gallery once through LDS (global_load_lds,
+//                    3-deep ring, counted vmcnt, raw s_barrier), multiplies each 32-row tile with
+//                    up to 256 register-resident queries on v_mfma_f32_32x32x16_bf16 and keeps only
+//                    the per-(query, tile) maximum ("bucket max") and per-(query, task) maximum.
+//   finalize_kernel  one workgroup per query: picks the KS best tasks, then the KS best tiles inside
+//                    them, then re-scores those KS*32 rows EXACTLY (fp64, fixed summation order
+//                    shared with oracle/search_ref.c) and orders them by (-dot, +row).  It certifies
+//                    that no excluded tile could hold a top-k row; uncertified queries are flagged.
+//   exh_* kernels    exhaustive exact fp64 path: fp32 galleries, unsupported E / large k, and any
+//                    query the certificate rejected.  Launched unconditionally; unflagged queries
+//                    exit at once, so there is no host round trip.
+// Why this is exact: every row with dot >= (k-th best dot) lives in a tile whose max is >= that
+// value; at most KS tiles can have such a max unless more than KS-k rows are within the MFMA
+// rounding error of the k-th -- which is exactly what the certificate checks.
+#include "mmr_common.h"
+
+#include <math.h>
+
+namespace mmr {
+
+constexpr int TILE_ROWS = 32;
+constexpr int SCAN_NBUF = 3;
+constexpr int MAX_TPT = 64;                 // tiles per task
+constexpr int KS_MAX = 32;                  // candidate tiles kept per query
+constexpr int K_MAX = 64;                   // largest k (exhaustive path)
+constexpr int FIN_THREADS = 256;
+
+__host__ __device__ static inline bool ranks_before(double sa, int64_t ia, double sb, int64_t ib) {
+    return sa > sb || (sa == sb && ia < ib);
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan
+// ---------------------------------------------------------------------------------------------
+// E <= 512: 8 waves x 32 queries (2 waves per SIMD, <= 256 VGPRs each).  E = 768 needs 192 VGPRs
+// for the resident queries alone, so it runs 4 waves x 32 queries at one wave per SIMD.
+template <int E>
+struct ScanCfg {
+    static constexpr int SCAN_WAVES = E <= 512 ? 8 : 4;
+    static constexpr int SCAN_THREADS = SCAN_WAVES * 64;
+    static constexpr int QMAX = SCAN_WAVES * 32;      // queries per scan pass
+    static constexpr int CH = E / 8;                  // 16-byte chunks per gallery row
+    static constexpr int ROWB = E * 2;                // bytes per row
+    static constexpr int TILE_BYTES = TILE_ROWS * ROWB;
+    static constexpr int LOADS = TILE_ROWS * CH / 64; // glds wave-instructions per tile
+    static constexpr int LPW = LOADS / SCAN_WAVES;    // per wave
+    static constexpr int KSTEPS = E / 16;
+    static_assert(LOADS % SCAN_WAVES == 0, "tile loads must split evenly over the waves");
+    static_assert(CH % 16 == 0, "XOR swizzle works on groups of 16 chunks");
+};
+
+template <int E>
+__global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 4) void scan_kernel(
+    const bf16_t *__restrict__ q, const bf16_t *__restrict__ gal, int Q, int64_t N, int ntiles, int tpt,
+    int qwaves, int qpad, float *__restrict__ bmax, float *__restrict__ tmax)
+{
+    using C = ScanCfg<E>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int task = blockIdx.x;
+    const int t0 = task * tpt;
+    const int t1 = min(ntiles, t0 + tpt);
+    const bool compute = wave < qwaves;
+
+    // B operand: this wave's 32 queries, resident for the whole task.  Lane (c,h) holds, for
+    // k-step s, the 8 elements [16s + 8h, 16s + 8h + 8) of query wave*32 + c.
+    bf16x8 bq[C::KSTEPS];
+    {
+        const int qrow = wave * 32 + c;
+        const bool live = compute && qrow < Q;
+        const bf16_t *qp = q + (size_t)(live ? qrow : 0) * E + h * 8;
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(qp + s * 16);
+            bq[s] = live ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    // Stage one 32-row tile: LDS slot p (16 B) of the tile holds chunk ((p%CH) ^ row) of row p/CH
+    // (XOR on the low 4 bits): the LDS image stays lane-linear for global_load_lds while
+    // ds_read_b128 of 32 different rows at one k offset is bank-conflict free.
+    auto stage = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < C::LPW; ++i) {
+            const int instr = wave * C::LPW + i;
+            const int p = instr * 64 + lane;
+            const int row = p / C::CH;
+            const int pos = p % C::CH;
+            const int chunk = (pos & ~15) | ((pos ^ row) & 15);
+            int64_t grow = (int64_t)tile * TILE_ROWS + row;
+            grow = grow < N ? grow : N - 1;  // clamp: rows past N are masked after the MFMA
+            glds16(gal + grow * E + chunk * 8, smem + buf * C::TILE_BYTES + instr * 1024);
+        }
+    };
+
+    const int rowoff = c * C::ROWB;
+
+    float task_max = -INFINITY;
+    float pend = -INFINITY;
+    int pend_tile = -1;
+
+    stage(t0, 0);
+    if (t0 + 1 < t1) stage(t0 + 1, 1);
+    int cur = 0;
+
+    for (int t = t0; t < t1; ++t) {
+        // this wave's loads of tile t have landed (tile t+1 may stay in flight) ...
+        if (t + 1 < t1) wait_vmcnt<C::LPW>(); else wait_vmcnt<0>();
+        // ... and after the barrier so have every other wave's.
+        __builtin_amdgcn_s_barrier();
+
+        if (compute && pend_tile >= 0 && h == 0) bmax[(size_t)pend_tile * qpad + wave * 32 + c] = pend;
+
+        int nxt = cur + 2; nxt = nxt >= SCAN_NBUF ? nxt - SCAN_NBUF : nxt;
+        if (t + 2 < t1) stage(t + 2, nxt);  // overwrites tile t-1's buffer: all waves are past it
+
+        if (compute) {
+            const char *tb = smem + cur * C::TILE_BYTES + rowoff;
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int s = 0; s < C::KSTEPS; ++s) {
+                const int chunk = 2 * s + h;
+                const int pos = (chunk & ~15) | ((chunk ^ c) & 15);
+                bf16x8 a = *reinterpret_cast<const bf16x8 *>(tb + pos * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[s], acc, 0, 0, 0);
+            }
+            // acc[i] = dot(query c, tile row (i&3) + 8*(i>>2) + 4*h)
+            float m = -INFINITY;
+            if ((int64_t)(t + 1) * TILE_ROWS <= N) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) m = fmaxf(m, acc[i]);
+            } else {
+                const int64_t base = (int64_t)t * TILE_ROWS + 4 * h;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t r = base + (i & 3) + 8 * (i >> 2);
+                    m = fmaxf(m, r < N ? acc[i] : -INFINITY);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            task_max = fmaxf(task_max, m);
+            pend = m;
+            pend_tile = t;
+        }
+        cur = cur + 1 >= SCAN_NBUF ? 0 : cur + 1;
+    }
+    if (compute && h == 0) {
+        if (pend_tile >= 0) bmax[(size_t)pend_tile * qpad + wave * 32 + c] = pend;
+        tmax[(size_t)task * qpad + wave * 32 + c] = task_max;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exact fp64 dot, shared by finalize / exhaustive / similarity
+// ---------------------------------------------------------------------------------------------
+template <typename T, int PER>
+__device__ __forceinline__ void load_lane_chunk(const T *row, int lane, float (&out)[PER]);
+
+template <int PER>
+__device__ __forceinline__ void load_lane_chunk_bf16(const bf16_t *row, int lane, float (&out)[PER]) {
+    const bf16_t *p = row + lane * PER;
+    if constexpr (PER % 8 == 0) {
+#pragma unroll
+        for (int v = 0; v < PER / 8; ++v) {
+            bf16x8 x = *reinterpret_cast<const bf16x8 *>(p + v * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[v * 8 + j] = bf16_to_f32((bf16_t)x[j]);
+        }
+    } else if constexpr (PER % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < PER / 4; ++v) {
+            uint2 x = *reinterpret_cast<const uint2 *>(p + v * 4);
+            out[v * 4 + 0] = __uint_as_float(x.x << 16);
+            out[v * 4 + 1] = __uint_as_float(x.x & 0xffff0000u);
+            out[v * 4 + 2] = __uint_as_float(x.y << 16);
+            out[v * 4 + 3] = __uint_as_float(x.y & 0xffff0000u);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) out[j] = bf16_to_f32(p[j]);
+    }
+}
+template <int PER>
+__device__ __forceinline__ void load_lane_chunk_f32(const float *row, int lane, float (&out)[PER]) {
+    const float *p = row + lane * PER;
+    if constexpr (PER % 4 == 0) {
+#pragma unroll
+        for (int v = 0; v < PER / 4; ++v) {
+            float4 x = *reinterpret_cast<const float4 *>(p + v * 4);
+            out[v * 4 + 0] = x.x; out[v * 4 + 1] = x.y; out[v * 4 + 2] = x.z; out[v * 4 + 3] = x.w;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < PER; ++j) out[j] = p[j];
+    }
+}
+template <typename T, int PER>
+__device__ __forceinline__ void load_chunk(const T *row, int lane, float (&out)[PER]) {
+    if constexpr (sizeof(T) == 2) load_lane_chunk_bf16<PER>((const bf16_t *)row, lane, out);
+    else load_lane_chunk_f32<PER>((const float *)row, lane, out);
+}
+
+// Lane l sums its PER contiguous elements left to right in fp64 (products are exact), then the
+// 64 partials meet in an xor-butterfly: the order oracle/search_ref.c replicates.
+template <int PER>
+__device__ __forceinline__ double exact_dot(const float (&qv)[PER], const float (&gv)[PER]) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) acc += (double)qv[j] * (double)gv[j];
+    return wave_sum_f64_butterfly(acc);
+}
+
+// ---------------------------------------------------------------------------------------------
+// workgroup selection: repeatedly extract the best (value, key) in (-value, +key) order
+// ---------------------------------------------------------------------------------------------
+struct SelScratch {
+    double v[FIN_THREADS / 64];
+    int64_t k[FIN_THREADS / 64];
+    double bv;
+    int64_t bk;
+};
+
+// get(i, &val, &key) -> bool valid.  Keys must be unique.  Writes `rounds` results (key -1 when
+// exhausted).  All threads of the workgroup must call it; results are visible to all after return.
+template <typename F>
+__device__ void wg_select(int n, int rounds, F get, double *out_v, int64_t *out_k, SelScratch *sc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double pv = INFINITY;
+    int64_t pk = -1;
+    for (int r = 0; r < rounds; ++r) {
+        double bv = -INFINITY;
+        int64_t bk = -1;
+        for (int i = tid; i < n; i += FIN_THREADS) {
+            double v;
+            int64_t key;
+            if (!get(i, v, key)) continue;
+            if (v != v) continue;  // NaN never ranks
+            if (r > 0 && !ranks_before(pv, pk, v, key)) continue;  // already taken (or equal to last pick)
+            if (bk < 0 || ranks_before(v, key, bv, bk)) { bv = v; bk = key; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            double ov = __shfl_xor(bv, off, 64);
+            int64_t ok = __shfl_xor(bk, off, 64);
+            if (ok >= 0 && (bk < 0 || ranks_before(ov, ok, bv, bk))) { bv = ov; bk = ok; }
+        }
+        if (lane == 0) { sc->v[wave] = bv; sc->k[wave] = bk; }
+        __syncthreads();
+        if (tid == 0) {
+            double fv = sc->v[0];
+            int64_t fk = sc->k[0];
+            for (int w = 1; w < FIN_THREADS / 64; ++w) {
+                if (sc->k[w] >= 0 && (fk < 0 || ranks_before(sc->v[w], sc->k[w], fv, fk))) { fv = sc->v[w]; fk = sc->k[w]; }
+            }
+            sc->bv = fv; sc->bk = fk;
+            out_v[r] = fk < 0 ? -INFINITY : fv;
+            out_k[r] = fk;
+        }
+        __syncthreads();
+        pv = sc->bv; pk = sc->bk;
+        if (pk < 0) {  // exhausted: fill the rest
+            if (tid == 0) for (int rr = r + 1; rr < rounds; ++rr) { out_v[rr] = -INFINITY; out_k[rr] = -1; }
+            __syncthreads();
+            return;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: one workgroup per query of the current chunk
+// ---------------------------------------------------------------------------------------------
+template <typename T, int PER>
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
+    const T *__restrict__ q, const T *__restrict__ gal, int64_t N, int k, int ks, int ntiles, int tpt,
+    int ntasks, int qpad, const float *__restrict__ bmax, const float *__restrict__ tmax, float scale,
+    float eps_coef, int32_t *__restrict__ idx, float *__restrict__ score, double *__restrict__ dot64,
+    int32_t *__restrict__ status, int32_t *__restrict__ need_exact)
+{
+    constexpr int E = PER * 64;
+    __shared__ SelScratch sc;
+    __shared__ double sel_v[KS_MAX + 1];
+    __shared__ int64_t sel_task[KS_MAX + 1];
+    __shared__ int64_t sel_tile[KS_MAX + 1];
+    __shared__ double cand_s[KS_MAX * TILE_ROWS];
+    __shared__ double out_v[K_MAX];
+    __shared__ int64_t out_k[K_MAX];
+
+    const int qi = blockIdx.x;  // query slot inside the chunk (q, idx... are already chunk-offset)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // level 1: best ks tasks (+1 to learn the best excluded one)
+    const int r1 = min(ks + 1, ntasks);
+    wg_select(ntasks, r1, [&](int i, double &v, int64_t &key) {
+        v = (double)tmax[(size_t)i * qpad + qi]; key = i; return true; }, sel_v, sel_task, &sc);
+    const int ntask_sel = min(ks, ntasks);
+    const double bound1 = (ntasks > ks) ? sel_v[ks] : -INFINITY;
+    __syncthreads();
+
+    // level 2: best ks tiles among the selected tasks' tiles, ordered by (-max, +tile)
+    const int n2 = ntask_sel * tpt;
+    const int r2 = ks + 1;
+    wg_select(n2, r2, [&](int i, double &v, int64_t &key) {
+        const int64_t task = sel_task[i / tpt];
+        if (task < 0) return false;
+        const int64_t tile = task * tpt + (i % tpt);
+        if (tile >= ntiles) return false;
+        v = (double)bmax[(size_t)tile * qpad + qi]; key = tile; return true; }, sel_v, sel_tile, &sc);
+    const double bound2 = sel_v[ks];  // -inf when fewer than ks+1 candidate tiles exist
+    __syncthreads();
+
+    // level 3: exact fp64 re-score of the candidate rows
+    float qv[PER];
+    load_chunk<T, PER>(q + (size_t)qi * E, lane, qv);
+    double qn2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) qn2 += (double)qv[j] * (double)qv[j];
+    qn2 = wave_sum_f64_butterfly(qn2);
+
+    const int ncand = ks * TILE_ROWS;
+    for (int j = wave; j < ncand; j += FIN_THREADS / 64) {
+        const int64_t tile = sel_tile[j / TILE_ROWS];
+        const int64_t row = tile * TILE_ROWS + (j % TILE_ROWS);
+        double s = -INFINITY;
+        if (tile >= 0 && row < N) {
+            float gv[PER];
+            load_chunk<T, PER>(gal + (size_t)row * E, lane, gv);
+            s = exact_dot<PER>(qv, gv);
+        }
+        if (lane == 0) cand_s[j] = s;
+    }
+    __syncthreads();
+
+    wg_select(ncand, k, [&](int i, double &v, int64_t &key) {
+        const int64_t tile = sel_tile[i / TILE_ROWS];
+        if (tile < 0) return false;
+        key = tile * TILE_ROWS + (i % TILE_ROWS);
+        if (key >= N) return false;
+        v = cand_s[i]; return true; }, out_v, out_k, &sc);
+
+    if (tid < k) {
+        const size_t o = (size_t)qi * k + tid;
+        idx[o] = (int32_t)out_k[tid];
+        score[o] = out_k[tid] < 0 ? -INFINITY : (float)(out_v[tid] * (double)scale);
+        if (dot64) dot64[o] = out_v[tid];
+    }
+    if (tid == 0) {
+        // Certificate: every excluded tile's max (an fp32 MFMA dot) is <= bound; a row of an excluded
+        // tile can only displace the k-th pick if its exact dot exceeds kth, i.e. if bound + err >= kth.
+        const double bound = fmax(bound1, bound2);
+        const double eps = (double)eps_coef * sqrt(qn2);
+        const int kk = (int)(N < k ? N : k);
+        const double kth = kk > 0 ? out_v[kk - 1] : INFINITY;
+        const bool ok = (bound == -INFINITY) || (out_k[kk > 0 ? kk - 1 : 0] >= 0 && kth > bound + eps);
+        need_exact[qi] = ok ? 0 : 1;
+        if (status) status[qi] = ok ? 0 : 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// exhaustive exact path
+// ---------------------------------------------------------------------------------------------
+struct ExhEntry { double s; int32_t i; int32_t pad; };
+
+// Insert a wave-uniform (s, id) into the lane-distributed sorted list (lane j = j-th best).
+__device__ __forceinline__ void list_insert(double &my_s, int32_t &my_i, double s, int32_t id, int lane) {
+    const bool before_me = ranks_before(s, id, my_s, my_i);
+    const double ps = __shfl_up(my_s, 1, 64);
+    const int32_t pi = __shfl_up(my_i, 1, 64);
+    if (before_me) {
+        const bool before_prev = lane > 0 && ranks_before(s, id, ps, pi);
+        my_s = before_prev ? ps : s;
+        my_i = before_prev ? pi : id;
+    }
+}
+
+template <typename T, int PER>
+__global__ __launch_bounds__(256) void exh_scan_kernel(
+    const T *__restrict__ q, const T *__restrict__ gal, int64_t N, int K, int nslab, int64_t rows_per_slab,
+    const int32_t *__restrict__ need_exact, ExhEntry *__restrict__ partial)
+{
+    constexpr int E = PER * 64;
+    __shared__ ExhEntry lists[4][K_MAX];
+    const int qi = blockIdx.y, slab = blockIdx.x;
+    if (need_exact && need_exact[qi] == 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    float qv[PER];
+    load_chunk<T, PER>(q + (size_t)qi * E, lane, qv);
+
+    double my_s = -INFINITY;
+    int32_t my_i = 0x7fffffff;
+    const int64_t r0 = (int64_t)slab * rows_per_slab;
+    const int64_t r1 = min(N, r0 + rows_per_slab);
+    for (int64_t r = r0 + wave; r < r1; r += 4) {
+        float gv[PER];
+        load_chunk<T, PER>(gal + (size_t)r * E, lane, gv);
+        const double s = exact_dot<PER>(qv, gv);
+        const double ts = __shfl(my_s, K - 1, 64);
+        const int32_t ti = __shfl(my_i, K - 1, 64);
+        if (s == s && ranks_before(s, (int32_t)r, ts, ti)) list_insert(my_s, my_i, s, (int32_t)r, lane);
+    }
+    lists[wave][lane] = ExhEntry{my_s, my_i, 0};
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < 4; ++w)
+            for (int j = 0; j < K; ++j) {
+                const ExhEntry e = lists[w][j];
+                if (e.i == 0x7fffffff) break;
+                const double ts = __shfl(my_s, K - 1, 64);
+                const int32_t ti = __shfl(my_i, K - 1, 64);
+                if (ranks_before(e.s, e.i, ts, ti)) list_insert(my_s, my_i, e.s, e.i, lane);
+            }
+        if (lane < K) partial[((size_t)qi * nslab + slab) * K + lane] = ExhEntry{my_s, my_i, 0};
+    }
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void exh_merge_kernel(
+    const ExhEntry *__restrict__ partial, int K, int k, int nslab, float scale,
+    const int32_t *__restrict__ need_exact, int32_t *__restrict__ idx, float *__restrict__ score,
+    double *__restrict__ dot64)
+{
+    __shared__ SelScratch sc;
+    __shared__ double out_v[K_MAX];
+    __shared__ int64_t out_k[K_MAX];
+    const int qi = blockIdx.x;
+    if (need_exact && need_exact[qi] == 0) return;
+    const ExhEntry *p = partial + (size_t)qi * nslab * K;
+    wg_select(nslab * K, k, [&](int i, double &v, int64_t &key) {
+        const ExhEntry e = p[i];
+        if (e.i == 0x7fffffff) return false;
+        v = e.s; key = e.i; return true; }, out_v, out_k, &sc);
+    const int tid = threadIdx.x;
+    if (tid < k) {
+        const size_t o = (size_t)qi * k + tid;
+        idx[o] = (int32_t)out_k[tid];
+        score[o] = out_k[tid] < 0 ? -INFINITY : (float)(out_v[tid] * (double)scale);
+        if (dot64) dot64[o] = out_v[tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense ops
+// ---------------------------------------------------------------------------------------------
+template <typename T, int PER>
+__global__ __launch_bounds__(256) void similarity_kernel(const T *__restrict__ q, const T *__restrict__ gal,
+                                                          int Q, int64_t N, float scale, float *__restrict__ out)
+{
+    constexpr int E = PER * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float gv[PER];
+    load_chunk<T, PER>(gal + (size_t)n * E, lane, gv);
+    for (int qi = 0; qi < Q; ++qi) {
+        float qv[PER];
+        load_chunk<T, PER>(q + (size_t)qi * E, lane, qv);
+        const double s = exact_dot<PER>(qv, gv);
+        if (lane == 0) out[(size_t)qi * N + n] = (float)(s * (double)scale);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_kernel(T *__restrict__ x, int64_t rows, int E)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+    if (r >= rows) return;
+    T *p = x + (size_t)r * E;
+    float ss = 0.f;
+    for (int j = lane; j < E; j += 64) {
+        float v;
+        if constexpr (sizeof(T) == 2) v = bf16_to_f32(((const bf16_t *)p)[j]); else v = ((const float *)p)[j];
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    const float inv = 1.0f / sqrtf(ss);
+    for (int j = lane; j < E; j += 64) {
+        if constexpr (sizeof(T) == 2) ((bf16_t *)p)[j] = f32_to_bf16(bf16_to_f32(((const bf16_t *)p)[j]) * inv);
+        else ((float *)p)[j] = ((const float *)p)[j] * inv;
+    }
+}
+
+__global__ void fill_empty_kernel(int32_t *idx, float *score, double *dot64, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        idx[i] = -1;
+        score[i] = -INFINITY;
+        if (dot64) dot64[i] = -INFINITY;
+    }
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void merge_kernel(const int64_t *__restrict__ idx_parts,
+                                                             const double *__restrict__ dot_parts, int parts, int Q,
+                                                             int k, float scale, int64_t *__restrict__ idx,
+                                                             float *__restrict__ score, double *__restrict__ dot64)
+{
+    __shared__ SelScratch sc;
+    __shared__ double out_v[K_MAX];
+    __shared__ int64_t out_k[K_MAX];
+    const int qi = blockIdx.x;
+    wg_select(parts * k, k, [&](int i, double &v, int64_t &key) {
+        const int p = i / k, c = i % k;
+        const size_t o = ((size_t)p * Q + qi) * k + c;
+        key = idx_parts[o];
+        if (key < 0) return false;
+        v = dot_parts[o]; return true; }, out_v, out_k, &sc);
+    const int tid = threadIdx.x;
+    if (tid < k) {
+        const size_t o = (size_t)qi * k + tid;
+        idx[o] = out_k[tid];
+        score[o] = out_k[tid] < 0 ? -INFINITY : (float)(out_v[tid] * (double)scale);
+        if (dot64) dot64[o] = out_k[tid] < 0 ? -INFINITY : out_v[tid];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct SearchPlan {
+    int ntiles, tpt, ntasks, nslab, ks;
+    int64_t rows_per_slab;
+    bool fast;  // MFMA scan usable
+    size_t off_bmax, off_tmax, off_flags, off_partial, total;
+};
+
+static bool scan_supports_E(int E) { return E == 128 || E == 256 || E == 512 || E == 768; }
+static int scan_qmax(int E) { return E <= 512 ? 256 : 128; }
+static bool exact_supports_E(int E) { return E == 128 || E == 256 || E == 512 || E == 768 || E == 1024; }
+
+static SearchPlan make_plan(int64_t N, int E, int Q, int k, mmr_dtype dt)
+{
+    SearchPlan p{};
+    p.ntiles = (int)((N + TILE_ROWS - 1) / TILE_ROWS);
+    if (p.ntiles <= 256) p.tpt = 1;
+    else {
+        const int m = (p.ntiles + 256 * MAX_TPT - 1) / (256 * MAX_TPT);
+        p.tpt = (p.ntiles + 256 * m - 1) / (256 * m);
+    }
+    p.ntasks = (p.ntiles + p.tpt - 1) / p.tpt;
+    p.ks = k + 6 > KS_MAX ? KS_MAX : k + 6;
+    p.fast = dt == MMR_BF16 && scan_supports_E(E) && k + 6 <= KS_MAX && N > 0;
+    int nslab = (int)((N + 2047) / 2048);
+    p.nslab = nslab < 1 ? 1 : (nslab > 64 ? 64 : nslab);
+    p.rows_per_slab = (N + p.nslab - 1) / p.nslab;
+    const int qc = Q < scan_qmax(E) ? (Q + 31) / 32 * 32 : scan_qmax(E);
+    size_t off = 0;
+    p.off_bmax = off; off += align_up((size_t)p.ntiles * qc * sizeof(float), 256);
+    p.off_tmax = off; off += align_up((size_t)p.ntasks * qc * sizeof(float), 256);
+    p.off_flags = off; off += align_up((size_t)(Q > 0 ? Q : 1) * sizeof(int32_t), 256);
+    p.off_partial = off; off += align_up((size_t)(Q > 0 ? Q : 1) * p.nslab * K_MAX * sizeof(ExhEntry), 256);
+    p.total = off;
+    return p;
+}
+
+template <int E>
+static int launch_scan(const bf16_t *q, const bf16_t *gal, int Qc, int64_t N, const SearchPlan &p, int qpad,
+                       float *bmax, float *tmax, hipStream_t st)
+{
+    using C = ScanCfg<E>;
+    const int lds = SCAN_NBUF * C::TILE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<E>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const int qwaves = qpad / 32;
+    hipLaunchKernelGGL(scan_kernel<E>, dim3(p.ntasks), dim3(C::SCAN_THREADS), lds, st, q, gal, Qc, N, p.ntiles, p.tpt,
+                       qwaves, qpad, bmax, tmax);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+template <typename T, int PER>
+static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, const SearchPlan &p, int qpad,
+                           const float *bmax, const float *tmax, float scale, float eps_coef, int32_t *idx,
+                           float *score, double *dot64, int32_t *status, int32_t *flags, hipStream_t st)
+{
+    hipLaunchKernelGGL((finalize_kernel<T, PER>), dim3(Qc), dim3(FIN_THREADS), 0, st, q, gal, N, k, p.ks, p.ntiles,
+                       p.tpt, p.ntasks, qpad, bmax, tmax, scale, eps_coef, idx, score, dot64, status, flags);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+template <typename T, int PER>
+static int launch_exh(const T *q, const T *gal, int Q, int64_t N, int k, const SearchPlan &p, float scale,
+                      const int32_t *flags, ExhEntry *partial, int32_t *idx, float *score, double *dot64,
+                      hipStream_t st)
+{
+    hipLaunchKernelGGL((exh_scan_kernel<T, PER>), dim3(p.nslab, Q), dim3(256), 0, st, q, gal, N, k, p.nslab,
+                       p.rows_per_slab, flags, partial);
+    MMR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(exh_merge_kernel, dim3(Q), dim3(FIN_THREADS), 0, st, partial, k, k, p.nslab, scale, flags, idx,
+                       score, dot64);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+#define MMR_DISPATCH_PER(E, T, ...)                                                    \
+    switch (E) {                                                                       \
+        case 128: { constexpr int PER = 2; __VA_ARGS__; } break;                              \
+        case 256: { constexpr int PER = 4; __VA_ARGS__; } break;                              \
+        case 512: { constexpr int PER = 8; __VA_ARGS__; } break;                              \
+        case 768: { constexpr int PER = 12; __VA_ARGS__; } break;                             \
+        case 1024: { constexpr int PER = 16; __VA_ARGS__; } break;                            \
+        default: mmr::set_error("E=%d unsupported (128,256,512,768,1024)", E); return MMR_ENOTSUP; \
+    }
+
+}  // namespace mmr
+
+using namespace mmr;
+
+extern "C" size_t mmr_search_workspace_bytes(int64_t N, int E, int Q, int k)
+{
+    if (N < 0 || Q < 0 || k < 1) return 0;
+    return make_plan(N, E, Q, k, MMR_BF16).total;
+}
+
+extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
+                               float scale, float gallery_norm_bound, int32_t *idx, float *score, double *dot64,
+                               int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MMR_CHECK_ARG(dtype == MMR_F32 || dtype == MMR_BF16, "mmr_cosine_topk: dtype %d", (int)dtype);
+    MMR_CHECK_ARG(Q >= 0 && N >= 0, "mmr_cosine_topk: negative size Q=%d N=%lld", Q, (long long)N);
+    MMR_CHECK_ARG(N < 0x7fffffff, "mmr_cosine_topk: N=%lld exceeds int32 row ids (shard the gallery)", (long long)N);
+    MMR_CHECK_ARG(k >= 1 && k <= K_MAX, "mmr_cosine_topk: k=%d outside [1,%d]", k, K_MAX);
+    MMR_CHECK_ARG(scale > 0.f, "mmr_cosine_topk: scale must be > 0 (got %g)", (double)scale);
+    MMR_CHECK_ARG(gallery_norm_bound > 0.f, "mmr_cosine_topk: gallery_norm_bound must be > 0");
+    if (!exact_supports_E(E)) { set_error("mmr_cosine_topk: E=%d unsupported (128,256,512,768,1024)", E); return MMR_ENOTSUP; }
+    if (Q == 0) return MMR_OK;
+    MMR_CHECK_ARG(q && idx && score && (gallery || N == 0), "mmr_cosine_topk: null pointer");
+    MMR_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)gallery & 15) == 0, "mmr_cosine_topk: q/gallery must be 16-byte aligned");
+    const SearchPlan p = make_plan(N, E, Q, k, dtype);
+    MMR_CHECK_ARG(workspace != nullptr, "mmr_cosine_topk: null workspace");
+    if (workspace_bytes < p.total) { set_error("mmr_cosine_topk: workspace %zu < required %zu", workspace_bytes, p.total); return MMR_ENOSPC; }
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *bmax = (float *)(ws + p.off_bmax);
+    float *tmax = (float *)(ws + p.off_tmax);
+    int32_t *flags = (int32_t *)(ws + p.off_flags);
+    ExhEntry *partial = (ExhEntry *)(ws + p.off_partial);
+    const size_t esz = dtype == MMR_BF16 ? 2 : 4;
+
+    if (N == 0) {  // nothing to rank: every slot is empty (idx -1, score -inf)
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((Q * k + 255) / 256), dim3(256), 0, st, idx, score, dot64, Q * k);
+        MMR_CHECK_LAUNCH();
+        if (status) MMR_CHECK_HIP(hipMemsetAsync(status, 0, (size_t)Q * sizeof(int32_t), st));
+        return MMR_OK;
+    }
+
+    if (p.fast) {
+        // fp32 MFMA accumulation error of a length-E bf16 dot is <= ~E*2^-24*|q||g|; the margin below
+        // is that worst case for E<=1024 with 25% headroom.  It gates the fast path only.
+        const float eps_coef = 8e-5f * gallery_norm_bound;
+        const int qmax = scan_qmax(E);
+        for (int q0 = 0; q0 < Q; q0 += qmax) {
+            const int Qc = (Q - q0) < qmax ? (Q - q0) : qmax;
+            const int qpad = (Qc + 31) / 32 * 32;
+            const bf16_t *qc = (const bf16_t *)q + (size_t)q0 * E;
+            int rc;
+            switch (E) {
+                case 128: rc = launch_scan<128>(qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                case 256: rc = launch_scan<256>(qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                case 512: rc = launch_scan<512>(qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                default: rc = launch_scan<768>(qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+            }
+            if (rc != MMR_OK) return rc;
+            MMR_DISPATCH_PER(E, bf16_t, {
+                rc = launch_finalize<bf16_t, PER>(qc, (const bf16_t *)gallery, Qc, N, k, p, qpad, bmax, tmax, scale,
+                                                  eps_coef, idx + (size_t)q0 * k, score + (size_t)q0 * k,
+                                                  dot64 ? dot64 + (size_t)q0 * k : nullptr,
+                                                  status ? status + q0 : nullptr, flags + q0, st);
+            });
+            if (rc != MMR_OK) return rc;
+        }
+        int rc;
+        MMR_DISPATCH_PER(E, bf16_t, {
+            rc = launch_exh<bf16_t, PER>((const bf16_t *)q, (const bf16_t *)gallery, Q, N, k, p, scale, flags, partial,
+                                         idx, score, dot64, st);
+        });
+        return rc;
+    }
+
+    if (status) {
+        // 1 = exhaustive path for every query
+        MMR_CHECK_HIP(hipMemsetD32Async((hipDeviceptr_t)status, 1, (size_t)Q, st));
+    }
+    int rc;
+    if (esz == 2) {
+        MMR_DISPATCH_PER(E, bf16_t, {
+            rc = launch_exh<bf16_t, PER>((const bf16_t *)q, (const bf16_t *)gallery, Q, N, k, p, scale, nullptr, partial,
+                                         idx, score, dot64, st);
+        });
+    } else {
+        MMR_DISPATCH_PER(E, float, {
+            rc = launch_exh<float, PER>((const float *)q, (const float *)gallery, Q, N, k, p, scale, nullptr, partial,
+                                        idx, score, dot64, st);
+        });
+    }
+    return rc;
+}
+
+extern "C" int mmr_similarity(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, float scale,
+                              float *out, void *stream)
+{
+    MMR_CHECK_ARG(dtype == MMR_F32 || dtype == MMR_BF16, "mmr_similarity: dtype %d", (int)dtype);
+    MMR_CHECK_ARG(Q >= 0 && N >= 0, "mmr_similarity: negative size");
+    if (Q == 0 || N == 0) return MMR_OK;
+    MMR_CHECK_ARG(q && gallery && out, "mmr_similarity: null pointer");
+    MMR_CHECK_ARG(((uintptr_t)q & 15) == 0 && ((uintptr_t)gallery & 15) == 0, "mmr_similarity: q/gallery must be 16-byte aligned");
+    MMR_CHECK_ARG((N + 3) / 4 < 0x7fffffff, "mmr_similarity: N too large");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((N + 3) / 4));
+    if (dtype == MMR_BF16) {
+        MMR_DISPATCH_PER(E, bf16_t, {
+            hipLaunchKernelGGL((similarity_kernel<bf16_t, PER>), grid, dim3(256), 0, st, (const bf16_t *)q,
+                               (const bf16_t *)gallery, Q, N, scale, out);
+        });
+    } else {
+        MMR_DISPATCH_PER(E, float, {
+            hipLaunchKernelGGL((similarity_kernel<float, PER>), grid, dim3(256), 0, st, (const float *)q,
+                               (const float *)gallery, Q, N, scale, out);
+        });
+    }
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+extern "C" int mmr_l2norm_rows(void *x, mmr_dtype dtype, int64_t rows, int E, void *stream)
+{
+    MMR_CHECK_ARG(dtype == MMR_F32 || dtype == MMR_BF16, "mmr_l2norm_rows: dtype %d", (int)dtype);
+    MMR_CHECK_ARG(rows >= 0 && E >= 1, "mmr_l2norm_rows: bad shape rows=%lld E=%d", (long long)rows, E);
+    if (rows == 0) return MMR_OK;
+    MMR_CHECK_ARG(x != nullptr, "mmr_l2norm_rows: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (dtype == MMR_BF16) hipLaunchKernelGGL(l2norm_kernel<bf16_t>, grid, dim3(256), 0, st, (bf16_t *)x, rows, E);
+    else hipLaunchKernelGGL(l2norm_kernel<float>, grid, dim3(256), 0, st, (float *)x, rows, E);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+extern "C" int mmr_topk_merge(const int64_t *idx_parts, const double *dot_parts, int parts, int Q, int k, float scale,
+                              int64_t *idx, float *score, double *dot64, void *stream)
+{
+    MMR_CHECK_ARG(parts >= 1 && Q >= 0 && k >= 1 && k <= K_MAX, "mmr_topk_merge: bad shape parts=%d Q=%d k=%d", parts, Q, k);
+    MMR_CHECK_ARG(scale > 0.f, "mmr_topk_merge: scale must be > 0");
+    if (Q == 0) return MMR_OK;
+    MMR_CHECK_ARG(idx_parts && dot_parts && idx && score, "mmr_topk_merge: null pointer");
+    hipLaunchKernelGGL(merge_kernel, dim3(Q), dim3(FIN_THREADS), 0, (hipStream_t)stream, idx_parts, dot_parts, parts, Q,
+                       k, scale, idx, score, dot64);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}

@@ -1,0 +1,195 @@
+"""GPU parity: HIP similarity / top-k (through the C ABI) vs the CPU oracle and the golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mmr_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S(device):
+    from mmr_amd import search
+    return search
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import search_ref
+    return search_ref
+
+
+def _gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "search.npz"))
+
+
+@pytest.mark.parametrize("N", [1000, 10000])
+@pytest.mark.parametrize("Q", [1, 7, 128])
+@pytest.mark.parametrize("tag", ["f32", "bf16"])
+def test_topk_matches_golden(S, device, golden_dir, N, Q, tag):
+    g = _gold(golden_dir)
+    key = f"N{N}_Q{Q}_{tag}"
+    gal = synth.synth_unit_rows(N, 512, seed=int(g["meta"][0]))
+    q = synth.synth_unit_rows(Q, 512, seed=int(g[key + "_qseed"]))
+    if tag == "bf16":
+        gal, q = gal.bfloat16(), q.bfloat16()
+    vals, idx, d64, status = S.cosine_topk(q.to(device), gal.to(device), 10, scale=100.0,
+                                           return_dot64=True, return_status=True)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int32), g[key + "_idx"])       # bit-exact ranks
+    assert np.array_equal(d64.cpu().numpy(), g[key + "_dot64"])                      # same fp64 order
+    assert np.array_equal(vals.cpu().numpy(), g[key + "_score"])
+    if tag == "bf16":
+        assert int(status.sum()) == 0, "tie-free fixture should certify on the MFMA fast path"
+    else:
+        assert int(status.sum()) == Q
+
+
+def test_tie_rule_lowest_index_first(S, device, golden_dir):
+    g = _gold(golden_dir)
+    gal = synth.synth_unit_rows(2048, 512, seed=int(g["meta"][1])).bfloat16()
+    q = synth.synth_unit_rows(5, 512, seed=int(g["meta"][2])).bfloat16()
+    gal[1500:1520] = gal[7]
+    gal[40] = gal[900]
+    q[0] = gal[7]
+    q[1] = gal[900]
+    vals, idx, d64 = S.cosine_topk(q.to(device), gal.to(device), 10, scale=100.0, return_dot64=True)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int32), g["ties_idx"])
+    assert np.array_equal(d64.cpu().numpy(), g["ties_dot64"])
+    assert idx[0].tolist() == [7] + list(range(1500, 1509))
+
+
+@pytest.mark.parametrize("E", [128, 256, 512, 768, 1024])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_topk_vs_oracle_shapes(S, oracle, device, E, dtype):
+    # ragged sizes: N not a multiple of the 32-row tile, Q not a multiple of 32, several k
+    for N, Q, k in [(1, 1, 1), (31, 3, 5), (33, 2, 10), (4097, 37, 10), (20011, 70, 20), (3000, 5, 30)]:
+        gal = synth.synth_unit_rows(N, E, seed=100 + N).to(dtype)
+        q = synth.synth_unit_rows(Q, E, seed=200 + Q).to(dtype)
+        vals, idx, d64 = S.cosine_topk(q.to(device), gal.to(device), k, scale=100.0, return_dot64=True)
+        oi, os_, od = oracle.cosine_topk(q, gal, k, scale=100.0)
+        assert np.array_equal(idx.cpu().numpy(), oi), (E, dtype, N, Q, k)
+        assert np.array_equal(d64.cpu().numpy(), od)
+        assert np.array_equal(vals.cpu().numpy(), os_)
+
+
+def test_topk_more_than_256_queries_and_k_gt_n(S, oracle, device):
+    gal = synth.synth_unit_rows(5000, 512, seed=7).bfloat16()
+    q = synth.synth_unit_rows(300, 512, seed=8).bfloat16()
+    vals, idx = S.cosine_topk(q.to(device), gal.to(device), 10)
+    oi, os_, _ = oracle.cosine_topk(q, gal, 10)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    small = gal[:4]
+    vals, idx = S.cosine_topk(q[:3].to(device), small.to(device), 8)
+    oi, os_, _ = oracle.cosine_topk(q[:3], small, 8)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert (idx[:, 4:] == -1).all() and torch.isinf(vals[:, 4:]).all()
+    # empty gallery
+    vals, idx = S.cosine_topk(q[:2].to(device), gal[:0].to(device), 3)
+    assert (idx == -1).all() and torch.isinf(vals).all()
+
+
+def test_uncertified_queries_fall_back_to_exact(S, oracle, device):
+    # 40 near-identical rows within bf16 rounding of each other straddle the top-k boundary:
+    # the certificate must reject the fast path and the exhaustive path must still be exact.
+    torch.manual_seed(0)
+    E = 512
+    gal = synth.synth_unit_rows(8192, E, seed=21).bfloat16()
+    base = gal[5].clone()
+    rows = torch.randperm(8192)[:60]
+    for j, r in enumerate(rows.tolist()):
+        v = base.clone()
+        bits = v.view(torch.int16)
+        bits[j] += (j % 5) - 2          # a few bf16 ulps on one component: dot moves by ~1e-5
+        gal[r] = v
+    q = base.unsqueeze(0).repeat(2, 1)
+    q[1] = synth.synth_unit_rows(1, E, seed=22).bfloat16()[0]
+    vals, idx, d64, status = S.cosine_topk(q.to(device), gal.to(device), 10, return_dot64=True, return_status=True)
+    oi, os_, od = oracle.cosine_topk(q, gal, 10)
+    assert np.array_equal(idx.cpu().numpy(), oi)
+    assert np.array_equal(d64.cpu().numpy(), od)
+    assert int(status[0]) == 1          # crowded boundary -> exact path
+    assert int(status[1]) == 0          # ordinary query -> fast path
+
+
+def test_similarity_and_l2norm(S, oracle, device):
+    gal = synth.synth_unit_rows(777, 512, seed=3) * 3.0
+    ref = synth.synth_unit_rows(4, 512, seed=4) * 0.5       # un-normalised query, like outlier_filter's mean
+    sim = S.similarity(gal.to(device), ref.to(device), 100.0)      # [N,Q]
+    osim = oracle.similarity(ref, gal, 100.0)                      # [Q,N]
+    assert sim.shape == (777, 4)
+    assert np.array_equal(sim.t().cpu().numpy(), osim)
+    one = S.similarity(gal.to(device), ref[0].to(device), 100.0)
+    assert one.shape == (777,)
+    assert np.array_equal(one.cpu().numpy(), osim[0])
+    # matches the reference's torch expression to fp32 rounding
+    assert torch.allclose(sim.cpu(), 100.0 * gal @ ref.t(), atol=2e-3)
+    for dt, tol in ((torch.float32, 2e-6), (torch.bfloat16, 1e-2)):
+        x = (torch.randn(33, 512) * 5).to(dt)
+        y = S.l2_normalize(x.to(device))
+        ref_n = oracle.l2norm_rows(x)
+        assert np.abs(y.float().cpu().numpy() - ref_n).max() <= tol
+    # in-place form used by callers: feats /= feats.norm(...)
+    x = torch.randn(5, 512, device=device)
+    y = S.l2_normalize(x, inplace=True)
+    assert y.data_ptr() == x.data_ptr() and torch.allclose(x.norm(dim=-1), torch.ones(5, device=device), atol=1e-5)
+
+
+def test_merge_equals_unsharded(S, oracle, device):
+    gal = synth.synth_unit_rows(6000, 512, seed=31).bfloat16()
+    q = synth.synth_unit_rows(9, 512, seed=32).bfloat16()
+    bounds = [0, 1000, 1001, 4000, 6000]
+    parts_i, parts_d = [], []
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        v, i, d = S.cosine_topk(q.to(device), gal[a:b].to(device), 10, return_dot64=True)
+        parts_i.append(torch.where(i >= 0, i + a, i))
+        parts_d.append(d)
+    v, i, d = S.merge_topk(torch.stack(parts_i), torch.stack(parts_d), 1.0)
+    oi, os_, od = oracle.cosine_topk(q, gal, 10)
+    assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od)
+
+
+def test_error_paths(S, device):
+    from mmr_amd._lib import MMRError
+    gal = torch.randn(10, 512, device=device)
+    with pytest.raises(MMRError):
+        S.cosine_topk(gal[:1], gal, 0)                  # k < 1
+    with pytest.raises(MMRError):
+        S.cosine_topk(gal[:1], gal, 10, scale=-1.0)     # scale must be positive
+    with pytest.raises(MMRError):
+        S.cosine_topk(torch.randn(1, 96, device=device), torch.randn(4, 96, device=device), 1)  # E unsupported
+    with pytest.raises(ValueError):
+        S.cosine_topk(torch.randn(1, 256, device=device), gal, 1)
+    with pytest.raises(RuntimeError):
+        S.cosine_topk(torch.randn(1, 512), torch.randn(4, 512), 1)  # CPU tensors: no CPU path
+
+
+@pytest.mark.slow
+def test_full_size_1m_gallery_exact(S, oracle, device):
+    """BASELINE cfg2 size: 1M x 512 bf16, Q=256, k=10 -- indices bit-exact vs the oracle on a query
+    sample, plus size-independent properties on all queries."""
+    N, E, Q, k = 1_000_000, 512, 256, 10
+    gal = synth.synth_unit_rows(N, E, seed=3, dtype=torch.bfloat16)
+    q = synth.synth_unit_rows(Q, E, seed=4, dtype=torch.bfloat16)
+    gd = gal.to(device)
+    vals, idx, d64, status = S.cosine_topk(q.to(device), gd, k, return_dot64=True, return_status=True)
+    idx_c, d_c = idx.cpu(), d64.cpu()
+    # properties: sorted by (-dot,+idx), ids unique and in range, dots re-computable from the rows
+    assert (d_c[:, :-1] >= d_c[:, 1:]).all()
+    assert ((idx_c >= 0) & (idx_c < N)).all()
+    assert all(len(set(r.tolist())) == k for r in idx_c)
+    rows = gal[idx_c.reshape(-1)].double().reshape(Q, k, E)
+    re = (rows * q.double().unsqueeze(1)).sum(-1)
+    assert (re - d_c).abs().max() < 1e-12
+    # idempotence: searching the gathered top-k rows alone returns the same order
+    sub = gd[idx[0]]
+    _, i2 = S.cosine_topk(q[:1].to(device), sub, k)
+    assert i2[0].tolist() == list(range(k))
+    # oracle on a sample of queries (exhaustive fp64 over 1M rows on the CPU)
+    sample = [0, 17, 255]
+    oi, _, od = oracle.cosine_topk(q[sample], gal, k)
+    assert np.array_equal(idx_c[sample].numpy(), oi)
+    assert np.array_equal(d_c[sample].numpy(), od)
+    print("status (queries on exhaustive path):", int(status.sum()))
