@@ -167,12 +167,11 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
 // ---------------------------------------------------------------------------------------------
 // exact fp64 dot, shared by finalize / exhaustive / similarity
 // ---------------------------------------------------------------------------------------------
-template <typename T, int PER>
-__device__ __forceinline__ void load_lane_chunk(const T *row, int lane, float (&out)[PER]);
-
+// A row of E elements is 64 contiguous chunks of PER = E/64 elements.  load_chunk fetches chunk
+// `c` (for a full-wave dot, c = lane).
 template <int PER>
-__device__ __forceinline__ void load_lane_chunk_bf16(const bf16_t *row, int lane, float (&out)[PER]) {
-    const bf16_t *p = row + lane * PER;
+__device__ __forceinline__ void load_chunk_bf16(const bf16_t *row, int c, float (&out)[PER]) {
+    const bf16_t *p = row + c * PER;
     if constexpr (PER % 8 == 0) {
 #pragma unroll
         for (int v = 0; v < PER / 8; ++v) {
@@ -195,8 +194,8 @@ __device__ __forceinline__ void load_lane_chunk_bf16(const bf16_t *row, int lane
     }
 }
 template <int PER>
-__device__ __forceinline__ void load_lane_chunk_f32(const float *row, int lane, float (&out)[PER]) {
-    const float *p = row + lane * PER;
+__device__ __forceinline__ void load_chunk_f32(const float *row, int c, float (&out)[PER]) {
+    const float *p = row + c * PER;
     if constexpr (PER % 4 == 0) {
 #pragma unroll
         for (int v = 0; v < PER / 4; ++v) {
@@ -209,71 +208,172 @@ __device__ __forceinline__ void load_lane_chunk_f32(const float *row, int lane, 
     }
 }
 template <typename T, int PER>
-__device__ __forceinline__ void load_chunk(const T *row, int lane, float (&out)[PER]) {
-    if constexpr (sizeof(T) == 2) load_lane_chunk_bf16<PER>((const bf16_t *)row, lane, out);
-    else load_lane_chunk_f32<PER>((const float *)row, lane, out);
+__device__ __forceinline__ void load_chunk(const T *row, int c, float (&out)[PER]) {
+    if constexpr (sizeof(T) == 2) load_chunk_bf16<PER>((const bf16_t *)row, c, out);
+    else load_chunk_f32<PER>((const float *)row, c, out);
 }
 
-// Lane l sums its PER contiguous elements left to right in fp64 (products are exact), then the
-// 64 partials meet in an xor-butterfly: the order oracle/search_ref.c replicates.
+// One chunk's partial: PER products summed left to right from 0.0 in fp64 (products are exact).
 template <int PER>
-__device__ __forceinline__ double exact_dot(const float (&qv)[PER], const float (&gv)[PER]) {
+__device__ __forceinline__ double chunk_partial(const float (&qv)[PER], const float (&gv)[PER]) {
     double acc = 0.0;
 #pragma unroll
     for (int j = 0; j < PER; ++j) acc += (double)qv[j] * (double)gv[j];
-    return wave_sum_f64_butterfly(acc);
+    return acc;
+}
+
+// Full-wave form: lane l owns chunk l; the 64 partials meet in an xor-butterfly (32,16,...,1):
+// the order oracle/search_ref.c replicates.
+template <int PER>
+__device__ __forceinline__ double exact_dot(const float (&qv)[PER], const float (&gv)[PER]) {
+    return wave_sum_f64_butterfly(chunk_partial<PER>(qv, gv));
+}
+
+// Quarter-wave form: 16 lanes own one row; lane m (0..15) owns chunks m, m+16, m+32, m+48.  The
+// butterfly's 32- and 16-steps pair exactly those chunks, so they become in-lane adds and only
+// the 8,4,2,1 steps cross lanes: bit-identical to exact_dot, four rows per wave pass.
+template <typename T, int PER>
+struct QuadQuery {
+    float v[4][PER];
+    __device__ __forceinline__ void load(const T *qrow, int m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_chunk<T, PER>(qrow, m + 16 * i, v[i]);
+    }
+};
+template <typename T, int PER>
+struct QuadRow {
+    float v[4][PER];
+    __device__ __forceinline__ void load(const T *grow, int m) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_chunk<T, PER>(grow, m + 16 * i, v[i]);
+    }
+};
+template <typename T, int PER>
+__device__ __forceinline__ double quad_dot(const QuadQuery<T, PER> &q, const QuadRow<T, PER> &g) {
+    const double p0 = chunk_partial<PER>(q.v[0], g.v[0]);
+    const double p1 = chunk_partial<PER>(q.v[1], g.v[1]);
+    const double p2 = chunk_partial<PER>(q.v[2], g.v[2]);
+    const double p3 = chunk_partial<PER>(q.v[3], g.v[3]);
+    double s = (p0 + p2) + (p1 + p3);   // butterfly steps 32 then 16
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) s = s + __shfl_xor(s, off, 64);
+    return s;
 }
 
 // ---------------------------------------------------------------------------------------------
-// workgroup selection: repeatedly extract the best (value, key) in (-value, +key) order
+// selection: extract the best (value, key) pairs in (-value, +key) order
 // ---------------------------------------------------------------------------------------------
+constexpr int32_t KEY_NONE = 0x7fffffff;
+constexpr int SEL_R = 16;                       // candidates per lane in the register path
+constexpr int SEL_FAST_MAX = SEL_R * FIN_THREADS;  // 4096
+
+template <typename V, typename K>
+__device__ __forceinline__ bool before(V sa, K ia, V sb, K ib) { return sa > sb || (sa == sb && ia < ib); }
+
+template <typename V>
 struct SelScratch {
-    double v[FIN_THREADS / 64];
-    int64_t k[FIN_THREADS / 64];
-    double bv;
-    int64_t bk;
+    V pv[FIN_THREADS / 64][K_MAX + 1];
+    int32_t pk[FIN_THREADS / 64][K_MAX + 1];
+    V bv;
+    int32_t bk;
 };
 
-// get(i, &val, &key) -> bool valid.  Keys must be unique.  Writes `rounds` results (key -1 when
-// exhausted).  All threads of the workgroup must call it; results are visible to all after return.
-template <typename F>
-__device__ void wg_select(int n, int rounds, F get, double *out_v, int64_t *out_k, SelScratch *sc) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double pv = INFINITY;
-    int64_t pk = -1;
+// `rounds` extractions from the R register candidates of each lane of ONE wave; lane 0 records
+// them.  Exhausted slots come out as (-inf, KEY_NONE).
+template <typename V, int R>
+__device__ __forceinline__ void wave_rounds(V (&v)[R], int32_t (&key)[R], int rounds, V *out_v, int32_t *out_k,
+                                            int lane) {
     for (int r = 0; r < rounds; ++r) {
-        double bv = -INFINITY;
-        int64_t bk = -1;
+        V bv = v[0];
+        int32_t bk = key[0];
+#pragma unroll
+        for (int j = 1; j < R; ++j)
+            if (before(v[j], key[j], bv, bk)) { bv = v[j]; bk = key[j]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const V ov = __shfl_xor(bv, off, 64);
+            const int32_t ok = __shfl_xor(bk, off, 64);
+            if (before(ov, ok, bv, bk)) { bv = ov; bk = ok; }
+        }
+        if (lane == 0) { out_v[r] = bv; out_k[r] = bk; }
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (key[j] == bk) { v[j] = (V)-INFINITY; key[j] = KEY_NONE; }
+    }
+}
+
+// Workgroup selection over n candidates.  get(i, v, key) -> bool valid; keys unique, < KEY_NONE.
+// n <= 4096: candidates live in registers, each wave extracts its own `rounds` winners, wave 0
+// merges the 4 lists (2 barriers in all).  Larger n: one global sweep per round (slow, rare).
+// Results land in out_v/out_k (shared memory) and are visible to every thread on return.
+template <typename V, typename F>
+__device__ void wg_select(int n, int rounds, F get, V *out_v, int32_t *out_k, SelScratch<V> *sc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = FIN_THREADS / 64;
+    if (n <= SEL_FAST_MAX) {
+        V v[SEL_R];
+        int32_t key[SEL_R];
+#pragma unroll
+        for (int j = 0; j < SEL_R; ++j) {
+            const int i = tid + j * FIN_THREADS;
+            V x = (V)-INFINITY;
+            int32_t kx = KEY_NONE;
+            if (i < n) {
+                V tv; int32_t tk;
+                if (get(i, tv, tk) && tv == tv) { x = tv; kx = tk; }
+            }
+            v[j] = x; key[j] = kx;
+        }
+        wave_rounds<V, SEL_R>(v, key, rounds, sc->pv[wave], sc->pk[wave], lane);
+        __syncthreads();
+        if (wave == 0) {
+            constexpr int R2 = (NW * (K_MAX + 1) + 63) / 64;
+            V v2[R2];
+            int32_t k2[R2];
+#pragma unroll
+            for (int j = 0; j < R2; ++j) {
+                const int cnd = lane + j * 64;
+                const bool ok = cnd < NW * rounds;
+                const int p = ok ? cnd / rounds : 0, rr = ok ? cnd % rounds : 0;
+                v2[j] = ok ? sc->pv[p][rr] : (V)-INFINITY;
+                k2[j] = ok ? sc->pk[p][rr] : KEY_NONE;
+            }
+            wave_rounds<V, R2>(v2, k2, rounds, out_v, out_k, lane);
+        }
+        __syncthreads();
+        return;
+    }
+    V pv = (V)INFINITY;
+    int32_t pk = -1;
+    for (int r = 0; r < rounds; ++r) {
+        V bv = (V)-INFINITY;
+        int32_t bk = KEY_NONE;
         for (int i = tid; i < n; i += FIN_THREADS) {
-            double v;
-            int64_t key;
-            if (!get(i, v, key)) continue;
-            if (v != v) continue;  // NaN never ranks
-            if (r > 0 && !ranks_before(pv, pk, v, key)) continue;  // already taken (or equal to last pick)
-            if (bk < 0 || ranks_before(v, key, bv, bk)) { bv = v; bk = key; }
+            V x; int32_t kx;
+            if (!get(i, x, kx) || !(x == x)) continue;
+            if (r > 0 && !before(pv, pk, x, kx)) continue;  // taken in an earlier round
+            if (before(x, kx, bv, bk)) { bv = x; bk = kx; }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) {
-            double ov = __shfl_xor(bv, off, 64);
-            int64_t ok = __shfl_xor(bk, off, 64);
-            if (ok >= 0 && (bk < 0 || ranks_before(ov, ok, bv, bk))) { bv = ov; bk = ok; }
+            const V ov = __shfl_xor(bv, off, 64);
+            const int32_t ok = __shfl_xor(bk, off, 64);
+            if (before(ov, ok, bv, bk)) { bv = ov; bk = ok; }
         }
-        if (lane == 0) { sc->v[wave] = bv; sc->k[wave] = bk; }
+        if (lane == 0) { sc->pv[wave][0] = bv; sc->pk[wave][0] = bk; }
         __syncthreads();
         if (tid == 0) {
-            double fv = sc->v[0];
-            int64_t fk = sc->k[0];
-            for (int w = 1; w < FIN_THREADS / 64; ++w) {
-                if (sc->k[w] >= 0 && (fk < 0 || ranks_before(sc->v[w], sc->k[w], fv, fk))) { fv = sc->v[w]; fk = sc->k[w]; }
-            }
+            V fv = sc->pv[0][0];
+            int32_t fk = sc->pk[0][0];
+            for (int w = 1; w < NW; ++w)
+                if (before(sc->pv[w][0], sc->pk[w][0], fv, fk)) { fv = sc->pv[w][0]; fk = sc->pk[w][0]; }
             sc->bv = fv; sc->bk = fk;
-            out_v[r] = fk < 0 ? -INFINITY : fv;
-            out_k[r] = fk;
+            out_v[r] = fv; out_k[r] = fk;
         }
         __syncthreads();
         pv = sc->bv; pk = sc->bk;
-        if (pk < 0) {  // exhausted: fill the rest
-            if (tid == 0) for (int rr = r + 1; rr < rounds; ++rr) { out_v[rr] = -INFINITY; out_k[rr] = -1; }
+        if (pk == KEY_NONE) {  // exhausted: the remaining slots are empty
+            if (tid == 0) for (int rr = r + 1; rr < rounds; ++rr) { out_v[rr] = (V)-INFINITY; out_k[rr] = KEY_NONE; }
             __syncthreads();
             return;
         }
@@ -291,80 +391,87 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     int32_t *__restrict__ status, int32_t *__restrict__ need_exact)
 {
     constexpr int E = PER * 64;
-    __shared__ SelScratch sc;
-    __shared__ double sel_v[KS_MAX + 1];
-    __shared__ int64_t sel_task[KS_MAX + 1];
-    __shared__ int64_t sel_tile[KS_MAX + 1];
+    __shared__ SelScratch<double> scd;
+    __shared__ SelScratch<float> scf;
+    __shared__ float sel_v[KS_MAX + 1];
+    __shared__ int32_t sel_task[KS_MAX + 1];
+    __shared__ int32_t sel_tile[KS_MAX + 1];
     __shared__ double cand_s[KS_MAX * TILE_ROWS];
     __shared__ double out_v[K_MAX];
-    __shared__ int64_t out_k[K_MAX];
+    __shared__ int32_t out_k[K_MAX];
 
     const int qi = blockIdx.x;  // query slot inside the chunk (q, idx... are already chunk-offset)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
 
     // level 1: best ks tasks (+1 to learn the best excluded one)
-    const int r1 = min(ks + 1, ntasks);
-    wg_select(ntasks, r1, [&](int i, double &v, int64_t &key) {
-        v = (double)tmax[(size_t)i * qpad + qi]; key = i; return true; }, sel_v, sel_task, &sc);
-    const int ntask_sel = min(ks, ntasks);
-    const double bound1 = (ntasks > ks) ? sel_v[ks] : -INFINITY;
+    wg_select<float>(ntasks, ks + 1, [&](int i, float &v, int32_t &key) {
+        v = tmax[(size_t)i * qpad + qi]; key = i; return true; }, sel_v, sel_task, &scf);
+    const float bound1 = sel_v[ks];  // -inf when no task was left out
     __syncthreads();
 
     // level 2: best ks tiles among the selected tasks' tiles, ordered by (-max, +tile)
-    const int n2 = ntask_sel * tpt;
-    const int r2 = ks + 1;
-    wg_select(n2, r2, [&](int i, double &v, int64_t &key) {
-        const int64_t task = sel_task[i / tpt];
-        if (task < 0) return false;
-        const int64_t tile = task * tpt + (i % tpt);
+    wg_select<float>(ks * tpt, ks + 1, [&](int i, float &v, int32_t &key) {
+        const int32_t task = sel_task[i / tpt];
+        if (task == KEY_NONE) return false;
+        const int32_t tile = task * tpt + (i % tpt);
         if (tile >= ntiles) return false;
-        v = (double)bmax[(size_t)tile * qpad + qi]; key = tile; return true; }, sel_v, sel_tile, &sc);
-    const double bound2 = sel_v[ks];  // -inf when fewer than ks+1 candidate tiles exist
+        v = bmax[(size_t)tile * qpad + qi]; key = tile; return true; }, sel_v, sel_tile, &scf);
+    const float bound2 = sel_v[ks];
     __syncthreads();
 
-    // level 3: exact fp64 re-score of the candidate rows
-    float qv[PER];
-    load_chunk<T, PER>(q + (size_t)qi * E, lane, qv);
+    // level 3: exact fp64 re-score of the candidate rows, 16 lanes per row, 4 rows in flight per lane
+    const int m = lane & 15;
+    QuadQuery<T, PER> qq;
+    qq.load(q + (size_t)qi * E, m);
     double qn2 = 0.0;
 #pragma unroll
-    for (int j = 0; j < PER; ++j) qn2 += (double)qv[j] * (double)qv[j];
-    qn2 = wave_sum_f64_butterfly(qn2);
+    for (int i = 0; i < 4; ++i) qn2 += chunk_partial<PER>(qq.v[i], qq.v[i]);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) qn2 += __shfl_xor(qn2, off, 64);
 
-    const int ncand = ks * TILE_ROWS;
-    for (int j = wave; j < ncand; j += FIN_THREADS / 64) {
-        const int64_t tile = sel_tile[j / TILE_ROWS];
-        const int64_t row = tile * TILE_ROWS + (j % TILE_ROWS);
-        double s = -INFINITY;
-        if (tile >= 0 && row < N) {
-            float gv[PER];
-            load_chunk<T, PER>(gal + (size_t)row * E, lane, gv);
-            s = exact_dot<PER>(qv, gv);
+    const int ncand = ks * TILE_ROWS;            // multiple of 32
+    const int grp = tid >> 4;                    // 16 row groups per pass
+    constexpr int UN = 2;
+    for (int j0 = 0; j0 < ncand; j0 += 16 * UN) {
+        QuadRow<T, PER> gr[UN];
+        bool live[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int j = j0 + u * 16 + grp;
+            const int32_t tile = sel_tile[j / TILE_ROWS];
+            const int64_t row = (int64_t)tile * TILE_ROWS + (j % TILE_ROWS);
+            live[u] = tile != KEY_NONE && row < N;
+            gr[u].load(gal + (size_t)(live[u] ? row : 0) * E, m);
         }
-        if (lane == 0) cand_s[j] = s;
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const double s = quad_dot<T, PER>(qq, gr[u]);
+            if (m == 0) cand_s[j0 + u * 16 + grp] = live[u] ? s : -INFINITY;
+        }
     }
     __syncthreads();
 
-    wg_select(ncand, k, [&](int i, double &v, int64_t &key) {
-        const int64_t tile = sel_tile[i / TILE_ROWS];
-        if (tile < 0) return false;
-        key = tile * TILE_ROWS + (i % TILE_ROWS);
-        if (key >= N) return false;
-        v = cand_s[i]; return true; }, out_v, out_k, &sc);
+    wg_select<double>(ncand, k, [&](int i, double &v, int32_t &key) {
+        const int32_t tile = sel_tile[i / TILE_ROWS];
+        if (tile == KEY_NONE) return false;
+        const int64_t row = (int64_t)tile * TILE_ROWS + (i % TILE_ROWS);
+        if (row >= N) return false;
+        key = (int32_t)row; v = cand_s[i]; return true; }, out_v, out_k, &scd);
 
     if (tid < k) {
         const size_t o = (size_t)qi * k + tid;
-        idx[o] = (int32_t)out_k[tid];
-        score[o] = out_k[tid] < 0 ? -INFINITY : (float)(out_v[tid] * (double)scale);
-        if (dot64) dot64[o] = out_v[tid];
+        const bool has = out_k[tid] != KEY_NONE;
+        idx[o] = has ? out_k[tid] : -1;
+        score[o] = has ? (float)(out_v[tid] * (double)scale) : -INFINITY;
+        if (dot64) dot64[o] = has ? out_v[tid] : -INFINITY;
     }
     if (tid == 0) {
         // Certificate: every excluded tile's max (an fp32 MFMA dot) is <= bound; a row of an excluded
-        // tile can only displace the k-th pick if its exact dot exceeds kth, i.e. if bound + err >= kth.
-        const double bound = fmax(bound1, bound2);
+        // tile can only displace the k-th pick if its exact dot reaches kth, i.e. if bound + err >= kth.
+        const double bound = (double)fmaxf(bound1, bound2);
         const double eps = (double)eps_coef * sqrt(qn2);
         const int kk = (int)(N < k ? N : k);
-        const double kth = kk > 0 ? out_v[kk - 1] : INFINITY;
-        const bool ok = (bound == -INFINITY) || (out_k[kk > 0 ? kk - 1 : 0] >= 0 && kth > bound + eps);
+        const bool ok = (bound == -INFINITY) || (out_k[kk - 1] != KEY_NONE && out_v[kk - 1] > bound + eps);
         need_exact[qi] = ok ? 0 : 1;
         if (status) status[qi] = ok ? 0 : 1;
     }
@@ -377,11 +484,11 @@ struct ExhEntry { double s; int32_t i; int32_t pad; };
 
 // Insert a wave-uniform (s, id) into the lane-distributed sorted list (lane j = j-th best).
 __device__ __forceinline__ void list_insert(double &my_s, int32_t &my_i, double s, int32_t id, int lane) {
-    const bool before_me = ranks_before(s, id, my_s, my_i);
+    const bool before_me = before(s, id, my_s, my_i);
     const double ps = __shfl_up(my_s, 1, 64);
     const int32_t pi = __shfl_up(my_i, 1, 64);
     if (before_me) {
-        const bool before_prev = lane > 0 && ranks_before(s, id, ps, pi);
+        const bool before_prev = lane > 0 && before(s, id, ps, pi);
         my_s = before_prev ? ps : s;
         my_i = before_prev ? pi : id;
     }
@@ -397,21 +504,32 @@ __global__ __launch_bounds__(256) void exh_scan_kernel(
     const int qi = blockIdx.y, slab = blockIdx.x;
     if (need_exact && need_exact[qi] == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, sub = lane >> 4;
 
-    float qv[PER];
-    load_chunk<T, PER>(q + (size_t)qi * E, lane, qv);
+    QuadQuery<T, PER> qq;
+    qq.load(q + (size_t)qi * E, m);
 
     double my_s = -INFINITY;
-    int32_t my_i = 0x7fffffff;
+    int32_t my_i = KEY_NONE;
     const int64_t r0 = (int64_t)slab * rows_per_slab;
     const int64_t r1 = min(N, r0 + rows_per_slab);
-    for (int64_t r = r0 + wave; r < r1; r += 4) {
-        float gv[PER];
-        load_chunk<T, PER>(gal + (size_t)r * E, lane, gv);
-        const double s = exact_dot<PER>(qv, gv);
-        const double ts = __shfl(my_s, K - 1, 64);
-        const int32_t ti = __shfl(my_i, K - 1, 64);
-        if (s == s && ranks_before(s, (int32_t)r, ts, ti)) list_insert(my_s, my_i, s, (int32_t)r, lane);
+    // each wave pass covers 4 consecutive rows (one per 16-lane group); waves interleave by 4 rows
+    for (int64_t rb = r0 + wave * 4; rb < r1; rb += 16) {
+        const int64_t r = rb + sub;
+        const bool live = r < r1;
+        QuadRow<T, PER> gr;
+        gr.load(gal + (size_t)(live ? r : rb) * E, m);
+        const double s = quad_dot<T, PER>(qq, gr);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const double sg = __shfl(s, 16 * g, 64);
+            const int64_t rg = rb + g;
+            if (rg < r1 && sg == sg) {
+                const double ts = __shfl(my_s, K - 1, 64);
+                const int32_t ti = __shfl(my_i, K - 1, 64);
+                if (before(sg, (int32_t)rg, ts, ti)) list_insert(my_s, my_i, sg, (int32_t)rg, lane);
+            }
+        }
     }
     lists[wave][lane] = ExhEntry{my_s, my_i, 0};
     __syncthreads();
@@ -419,10 +537,10 @@ __global__ __launch_bounds__(256) void exh_scan_kernel(
         for (int w = 1; w < 4; ++w)
             for (int j = 0; j < K; ++j) {
                 const ExhEntry e = lists[w][j];
-                if (e.i == 0x7fffffff) break;
+                if (e.i == KEY_NONE) break;
                 const double ts = __shfl(my_s, K - 1, 64);
                 const int32_t ti = __shfl(my_i, K - 1, 64);
-                if (ranks_before(e.s, e.i, ts, ti)) list_insert(my_s, my_i, e.s, e.i, lane);
+                if (before(e.s, e.i, ts, ti)) list_insert(my_s, my_i, e.s, e.i, lane);
             }
         if (lane < K) partial[((size_t)qi * nslab + slab) * K + lane] = ExhEntry{my_s, my_i, 0};
     }
@@ -433,22 +551,23 @@ __global__ __launch_bounds__(FIN_THREADS) void exh_merge_kernel(
     const int32_t *__restrict__ need_exact, int32_t *__restrict__ idx, float *__restrict__ score,
     double *__restrict__ dot64)
 {
-    __shared__ SelScratch sc;
+    __shared__ SelScratch<double> sc;
     __shared__ double out_v[K_MAX];
-    __shared__ int64_t out_k[K_MAX];
+    __shared__ int32_t out_k[K_MAX];
     const int qi = blockIdx.x;
     if (need_exact && need_exact[qi] == 0) return;
     const ExhEntry *p = partial + (size_t)qi * nslab * K;
-    wg_select(nslab * K, k, [&](int i, double &v, int64_t &key) {
+    wg_select<double>(nslab * K, k, [&](int i, double &v, int32_t &key) {
         const ExhEntry e = p[i];
-        if (e.i == 0x7fffffff) return false;
+        if (e.i == KEY_NONE) return false;
         v = e.s; key = e.i; return true; }, out_v, out_k, &sc);
     const int tid = threadIdx.x;
     if (tid < k) {
         const size_t o = (size_t)qi * k + tid;
-        idx[o] = (int32_t)out_k[tid];
-        score[o] = out_k[tid] < 0 ? -INFINITY : (float)(out_v[tid] * (double)scale);
-        if (dot64) dot64[o] = out_v[tid];
+        const bool has = out_k[tid] != KEY_NONE;
+        idx[o] = has ? out_k[tid] : -1;
+        score[o] = has ? (float)(out_v[tid] * (double)scale) : -INFINITY;
+        if (dot64) dot64[o] = has ? out_v[tid] : -INFINITY;
     }
 }
 
@@ -504,27 +623,51 @@ __global__ void fill_empty_kernel(int32_t *idx, float *score, double *dot64, int
     }
 }
 
-__global__ __launch_bounds__(FIN_THREADS) void merge_kernel(const int64_t *__restrict__ idx_parts,
-                                                             const double *__restrict__ dot_parts, int parts, int Q,
-                                                             int k, float scale, int64_t *__restrict__ idx,
-                                                             float *__restrict__ score, double *__restrict__ dot64)
+// parts*k <= 8*64 candidates with int64 global ids: one wave, candidates in registers.
+__global__ __launch_bounds__(64) void merge_kernel(const int64_t *__restrict__ idx_parts,
+                                                    const double *__restrict__ dot_parts, int parts, int Q, int k,
+                                                    float scale, int64_t *__restrict__ idx, float *__restrict__ score,
+                                                    double *__restrict__ dot64)
 {
-    __shared__ SelScratch sc;
-    __shared__ double out_v[K_MAX];
-    __shared__ int64_t out_k[K_MAX];
-    const int qi = blockIdx.x;
-    wg_select(parts * k, k, [&](int i, double &v, int64_t &key) {
-        const int p = i / k, c = i % k;
-        const size_t o = ((size_t)p * Q + qi) * k + c;
-        key = idx_parts[o];
-        if (key < 0) return false;
-        v = dot_parts[o]; return true; }, out_v, out_k, &sc);
-    const int tid = threadIdx.x;
-    if (tid < k) {
-        const size_t o = (size_t)qi * k + tid;
-        idx[o] = out_k[tid];
-        score[o] = out_k[tid] < 0 ? -INFINITY : (float)(out_v[tid] * (double)scale);
-        if (dot64) dot64[o] = out_k[tid] < 0 ? -INFINITY : out_v[tid];
+    constexpr int R = 16;  // 64 lanes * 16 = 1024 candidates >= MERGE_MAX_PARTS * K_MAX
+    const int qi = blockIdx.x, lane = threadIdx.x;
+    const int n = parts * k;
+    double v[R];
+    int64_t key[R];
+    constexpr int64_t NONE = 0x7fffffffffffffffLL;
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int i = lane + j * 64;
+        v[j] = -INFINITY; key[j] = NONE;
+        if (i < n) {
+            const size_t o = ((size_t)(i / k) * Q + qi) * k + (i % k);
+            const int64_t gi = idx_parts[o];
+            const double d = dot_parts[o];
+            if (gi >= 0 && d == d) { v[j] = d; key[j] = gi; }
+        }
+    }
+    for (int r = 0; r < k; ++r) {
+        double bv = v[0];
+        int64_t bk = key[0];
+#pragma unroll
+        for (int j = 1; j < R; ++j)
+            if (before(v[j], key[j], bv, bk)) { bv = v[j]; bk = key[j]; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int64_t ok = __shfl_xor(bk, off, 64);
+            if (before(ov, ok, bv, bk)) { bv = ov; bk = ok; }
+        }
+        if (lane == 0) {
+            const size_t o = (size_t)qi * k + r;
+            const bool has = bk != NONE;
+            idx[o] = has ? bk : -1;
+            score[o] = has ? (float)(bv * (double)scale) : -INFINITY;
+            if (dot64) dot64[o] = has ? bv : -INFINITY;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            if (key[j] == bk) { v[j] = -INFINITY; key[j] = NONE; }
     }
 }
 
@@ -762,8 +905,9 @@ extern "C" int mmr_topk_merge(const int64_t *idx_parts, const double *dot_parts,
     MMR_CHECK_ARG(scale > 0.f, "mmr_topk_merge: scale must be > 0");
     if (Q == 0) return MMR_OK;
     MMR_CHECK_ARG(idx_parts && dot_parts && idx && score, "mmr_topk_merge: null pointer");
-    hipLaunchKernelGGL(merge_kernel, dim3(Q), dim3(FIN_THREADS), 0, (hipStream_t)stream, idx_parts, dot_parts, parts, Q,
-                       k, scale, idx, score, dot64);
+    MMR_CHECK_ARG(parts * k <= 1024, "mmr_topk_merge: parts*k=%d exceeds 1024", parts * k);
+    hipLaunchKernelGGL(merge_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, idx_parts, dot_parts, parts, Q, k,
+                       scale, idx, score, dot64);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
