@@ -128,6 +128,20 @@ int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_dtype, int B
                       mmr_dtype out_dtype, int normalize, int tap_after, float *tap, void *workspace,
                       size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Kernel-level test hooks (used by tests/ to localise a parity failure; not part of the drop-in).
+ * ---------------------------------------------------------------------------------------- */
+
+/* out[M,N] = epilogue(A[M,K] . W[N,K]^T): epi 0 = +bias -> bf16, 1 = +bias, QuickGELU -> bf16,
+ * 2 = fp32 out += acc + bias, 3 = plain fp32.  M,N multiples of 128, K multiple of 64. */
+int mmr_debug_gemm(int epi, const void *A, const void *W, int M, int N, int K, const float *bias, void *out,
+                   void *stream);
+/* x_bf16[rows,d] = LayerNorm(h_f32[rows,d]) */
+int mmr_debug_layernorm(const float *h, const float *w, const float *b, void *x, int64_t rows, int d, float eps,
+                        void *stream);
+/* o_bf16[B*T, d] = softmax(QK^T/8 (+causal)) V per head, from packed qkv_bf16[B*T, 3d] */
+int mmr_debug_attention(const void *qkv, void *o, int B, int T, int heads, int causal, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,12 @@ def lib():
         L.mmr_text_encode.argtypes = [vp, vp, i32, vp, i32, i32, vp, sz, vp]
         L.mmr_tower_forward.restype = i32
         L.mmr_tower_forward.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, sz, vp]
+        L.mmr_debug_gemm.restype = i32
+        L.mmr_debug_gemm.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp]
+        L.mmr_debug_layernorm.restype = i32
+        L.mmr_debug_layernorm.argtypes = [vp, vp, vp, vp, i64, i32, f32, vp]
+        L.mmr_debug_attention.restype = i32
+        L.mmr_debug_attention.argtypes = [vp, vp, i32, i32, i32, i32, vp]
     _lib = L
     return L
 

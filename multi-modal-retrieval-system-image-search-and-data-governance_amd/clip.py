@@ -1,0 +1,339 @@
+"""``clip``-package call surface over the HIP towers.
+
+Mirrors what the reference scripts do with the third-party ``clip`` / ``transformers`` objects:
+    model, preprocess = clip.load("ViT-B/32", device=device)       reference code/test_clip.py:6
+    text = clip.tokenize([...]).to(device)                         reference code/test_clip.py:9
+    model.encode_image(image) / model.encode_text(text)            reference code/test_clip.py:12-13
+    logits_per_image, logits_per_text = model(image, text)         reference code/test_clip.py:15
+    model.get_image_features(pixel_values=...) ; model.logit_scale reference code/test_taiyi.py:23,29
+    model.dtype / .eval() / .cuda() / .float()                     reference code/main_custom.py:151
+All arithmetic is in csrc/*.hip behind include/mmr.h; this file only owns tensors and handles.
+No autograd: every reference call site wraps the encoder in ``torch.no_grad()``.
+"""
+import ctypes
+from typing import Dict, List, Optional, Union
+
+import torch
+
+from . import _lib
+from .config import ClipConfig, TowerConfig, available_models, get_config  # noqa: F401
+from .weights import make_clip_weights
+
+_CONTEXT = 77
+# preprocessing constants the reference carries in code/custom.py:28
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def _tower_cfg_struct(t: TowerConfig) -> _lib.TowerCfg:
+    return _lib.TowerCfg(kind=0 if t.kind == "vision" else 1, width=t.width, layers=t.layers, heads=t.heads,
+                         mlp=t.mlp, tokens=t.tokens, embed_dim=t.embed_dim, image_size=t.image_size,
+                         patch=t.patch, vocab=t.vocab, ln_eps=t.ln_eps)
+
+
+class _Tower:
+    """One device-resident tower: weight blob + C handle + reusable workspace."""
+
+    _LAYER_PARAMS = (("ln1.w", _lib.P_LN1_W, False), ("ln1.b", _lib.P_LN1_B, False),
+                     ("qkv.w", _lib.P_QKV_W, True), ("qkv.b", _lib.P_QKV_B, False),
+                     ("out.w", _lib.P_OUT_W, True), ("out.b", _lib.P_OUT_B, False),
+                     ("ln2.w", _lib.P_LN2_W, False), ("ln2.b", _lib.P_LN2_B, False),
+                     ("fc1.w", _lib.P_FC1_W, True), ("fc1.b", _lib.P_FC1_B, False),
+                     ("fc2.w", _lib.P_FC2_W, True), ("fc2.b", _lib.P_FC2_B, False))
+
+    def __init__(self, cfg: TowerConfig, w: Dict[str, torch.Tensor], device: torch.device):
+        self.cfg, self.device = cfg, device
+        self.L = _lib.lib()
+        self.c = _tower_cfg_struct(cfg)
+        total = self.L.mmr_tower_weights_bytes(ctypes.byref(self.c))
+        if total == 0:
+            raise _lib.MMRError(-22, f"unsupported tower geometry {cfg}")
+        blob = torch.zeros(total, dtype=torch.uint8)           # host staging, then one H2D copy
+        pre = "v" if cfg.kind == "vision" else "t"
+
+        def put(param, layer, tensor, as_bf16):
+            off, nbytes = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(self.L.mmr_tower_param_span(ctypes.byref(self.c), param, layer, ctypes.byref(off),
+                                                   ctypes.byref(nbytes)))
+            t = tensor.detach().to("cpu").contiguous()
+            t = t.to(torch.bfloat16) if as_bf16 else t.to(torch.float32)
+            raw = t.view(torch.uint8).reshape(-1)
+            if raw.numel() != nbytes.value:
+                raise ValueError(f"tensor for param {param} has {raw.numel()} bytes, layout wants {nbytes.value}")
+            blob[off.value:off.value + nbytes.value] = raw
+
+        if cfg.kind == "vision":
+            pw = w["v.patch_w"].reshape(cfg.width, -1)
+            pad = torch.zeros(cfg.width, cfg.patch_k_pad, dtype=pw.dtype)
+            pad[:, :cfg.patch_k] = pw
+            put(_lib.P_PATCH_W, 0, pad, True)
+            put(_lib.P_CLS, 0, w["v.cls"], False)
+            put(_lib.P_POS, 0, w["v.pos"], False)
+            put(_lib.P_LN_PRE_W, 0, w["v.ln_pre.w"], False)
+            put(_lib.P_LN_PRE_B, 0, w["v.ln_pre.b"], False)
+            put(_lib.P_LN_FINAL_W, 0, w["v.ln_post.w"], False)
+            put(_lib.P_LN_FINAL_B, 0, w["v.ln_post.b"], False)
+            put(_lib.P_PROJ, 0, w["v.proj"], True)
+        else:
+            put(_lib.P_TOK_EMB, 0, w["t.tok"], True)
+            put(_lib.P_POS, 0, w["t.pos"], False)
+            put(_lib.P_LN_FINAL_W, 0, w["t.ln_final.w"], False)
+            put(_lib.P_LN_FINAL_B, 0, w["t.ln_final.b"], False)
+            put(_lib.P_PROJ, 0, w["t.proj"], True)
+        for i in range(cfg.layers):
+            for name, pid, bf in self._LAYER_PARAMS:
+                put(pid, i, w[f"{pre}.l{i}.{name}"], bf)
+
+        self.blob = blob.to(device)
+        handle = ctypes.c_void_p()
+        _lib.check(self.L.mmr_tower_create(ctypes.byref(self.c), self.blob.data_ptr(), self.blob.numel(),
+                                           ctypes.byref(handle)))
+        self.handle = handle
+        self._ws = None
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                self.L.mmr_tower_destroy(h)
+            except Exception:
+                pass
+
+    def workspace(self, batch: int) -> torch.Tensor:
+        need = self.L.mmr_tower_workspace_bytes(self.handle, batch)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, inp: torch.Tensor, out_dtype: torch.dtype, normalize: bool, tap_after: int = -1,
+                tap: Optional[torch.Tensor] = None) -> torch.Tensor:
+        B = inp.shape[0]
+        out = torch.empty(B, self.cfg.embed_dim, dtype=out_dtype, device=self.device)
+        if B == 0:
+            return out
+        ws = self.workspace(B)
+        in_code = _lib.dtype_code(inp.dtype) if self.cfg.kind == "vision" else _lib.MMR_F32
+        _lib.check(self.L.mmr_tower_forward(self.handle, inp.data_ptr(), in_code, B, out.data_ptr(),
+                                            _lib.dtype_code(out_dtype), int(bool(normalize)), int(tap_after),
+                                            _lib.ptr(tap), ws.data_ptr(), ws.numel(), _lib.stream_ptr(self.device)))
+        return out
+
+
+class CLIP:
+    """Drop-in for the object ``clip.load`` returns (and for HF ``CLIPModel`` where the reference
+    uses ``get_image_features`` / ``logit_scale``)."""
+
+    max_batch = 512   # images (or texts) per launch sequence; larger inputs are processed in slices
+
+    def __init__(self, cfg: ClipConfig, weights: Dict[str, torch.Tensor], device="cuda"):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("this CLIP runs on MI355X only (device must be 'cuda'); there is no CPU path")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.cfg, self.device = cfg, device
+        with torch.cuda.device(device):
+            self.visual = _Tower(cfg.vision, weights, device)
+            self.text = _Tower(cfg.text, weights, device)
+        self.logit_scale = weights["logit_scale"].detach().clone().to(device=device, dtype=torch.float32)
+        # Output dtype.  Arithmetic is always bf16-in / fp32-accumulate MFMA; the RETURNED tensors default
+        # to float32 because the reference's callers do `.cpu().numpy()` on them
+        # (code/search_image.py:109,158), which numpy cannot do for bf16.  `.bfloat16()` switches the
+        # outputs to bf16 -- the gallery storage type of the search path.
+        self._dtype = torch.float32
+        self.training = False
+
+    # ---- nn.Module-ish surface the reference touches
+    @property
+    def dtype(self) -> torch.dtype:
+        return self._dtype
+
+    @property
+    def input_resolution(self) -> int:
+        return self.cfg.vision.image_size
+
+    @property
+    def context_length(self) -> int:
+        return self.cfg.text.tokens
+
+    def eval(self):
+        return self
+
+    def train(self, mode: bool = False):
+        if mode:
+            raise RuntimeError("inference-only model: every reference call site runs it under torch.no_grad()")
+        return self
+
+    def requires_grad_(self, flag: bool = False):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    def to(self, *args, **kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.dtype):
+                self._set_dtype(a)
+            elif isinstance(a, (str, torch.device)) and torch.device(a).type != "cuda":
+                raise RuntimeError("this CLIP cannot leave the GPU; there is no CPU path")
+        return self
+
+    def float(self):
+        """Features come back as float32 (the default; arithmetic stays bf16-in / fp32-accumulate MFMA)."""
+        return self._set_dtype(torch.float32)
+
+    def bfloat16(self):
+        return self._set_dtype(torch.bfloat16)
+
+    def half(self):
+        raise RuntimeError("fp16 is not built for gfx950 here; use bfloat16 (default) or float()")
+
+    def _set_dtype(self, dt):
+        if dt not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"model dtype must be float32 or bfloat16, got {dt}")
+        self._dtype = dt
+        return self
+
+    # ---- encoders
+    def _prep_pixels(self, image: torch.Tensor) -> torch.Tensor:
+        if image.dim() != 4 or image.shape[1] != 3:
+            raise ValueError(f"expected pixels [B,3,H,W], got {tuple(image.shape)}")
+        S = self.cfg.vision.image_size
+        if image.shape[2] != S or image.shape[3] != S:
+            # same failure the HF tower raises (modeling_clip.py:204-207)
+            raise ValueError(f"Input image size ({image.shape[2]}*{image.shape[3]}) doesn't match model ({S}*{S}).")
+        if image.dtype not in (torch.float32, torch.bfloat16):
+            image = image.to(torch.float32)
+        return image.to(self.device).contiguous()
+
+    @torch.no_grad()
+    def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """[B,3,S,S] -> [B,E] in ``self.dtype``; a fresh, writable tensor (callers do ``/=`` on it)."""
+        px = self._prep_pixels(image)
+        with torch.cuda.device(self.device):
+            outs = [self.visual.forward(px[s:s + self.max_batch], self._dtype, normalize)
+                    for s in range(0, px.shape[0], self.max_batch)]
+        return outs[0] if len(outs) == 1 else torch.cat(outs) if outs else \
+            torch.empty(0, self.cfg.embed_dim, dtype=self._dtype, device=self.device)
+
+    def _prep_ids(self, text: torch.Tensor) -> torch.Tensor:
+        if text is None:
+            raise ValueError("You have to specify input_ids")      # modeling_clip.py:535-536
+        text = torch.as_tensor(text)
+        if text.dim() == 1:
+            text = text.unsqueeze(0)
+        T = self.cfg.text.tokens
+        if text.dim() != 2 or text.shape[1] != T:
+            raise ValueError(f"expected token ids [N,{T}], got {tuple(text.shape)}")
+        if text.dtype.is_floating_point:
+            raise TypeError("token ids must be an integer tensor")
+        if text.numel() and (int(text.min()) < 0 or int(text.max()) >= self.cfg.text.vocab):
+            raise IndexError(f"token id outside [0,{self.cfg.text.vocab})")
+        return text.to(device=self.device, dtype=torch.int32).contiguous()
+
+    @torch.no_grad()
+    def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
+        """int [N,77] -> [N,E]; pooled at the EOT token = ``text.argmax(-1)``."""
+        ids = self._prep_ids(text)
+        with torch.cuda.device(self.device):
+            outs = [self.text.forward(ids[s:s + self.max_batch], self._dtype, normalize)
+                    for s in range(0, ids.shape[0], self.max_batch)]
+        return outs[0] if len(outs) == 1 else torch.cat(outs) if outs else \
+            torch.empty(0, self.cfg.embed_dim, dtype=self._dtype, device=self.device)
+
+    # HF spellings (reference code/test_taiyi.py:23, CLIP-Chinese/lab_chinese.py:114)
+    def get_image_features(self, pixel_values: torch.Tensor = None, **_):
+        return self.encode_image(pixel_values)
+
+    def get_text_features(self, input_ids: torch.Tensor = None, **_):
+        return self.encode_text(input_ids)
+
+    @torch.no_grad()
+    def forward(self, image: torch.Tensor, text: torch.Tensor):
+        """-> (logits_per_image [B,N], logits_per_text [N,B]) = exp(logit_scale) * I_n @ T_n^T."""
+        from .search import similarity
+
+        img = self.encode_image(image, normalize=True).to(torch.float32)
+        txt = self.encode_text(text, normalize=True).to(torch.float32)
+        scale = float(self.logit_scale.exp())
+        logits_per_image = similarity(img, txt, scale)            # [B,N] = img @ txt.T * scale
+        if logits_per_image.dim() == 1:
+            logits_per_image = logits_per_image.unsqueeze(1)
+        return logits_per_image.contiguous(), logits_per_image.t().contiguous()      # fp32, like CPU clip
+
+    __call__ = forward
+
+
+def _preprocess_factory(n_px: int):
+    """Host-side stand-in for the ``preprocess`` transform ``clip.load`` returns: bicubic resize of
+    the shorter side to n_px, centre crop, /255, normalise with the CLIP mean/std
+    (reference code/custom.py:28; use sites code/search_image.py:127,155).  Accepts a PIL image, an
+    HWC uint8 array, or a CHW tensor.  Data loading is outside the hot path."""
+    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
+    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+
+    def preprocess(img) -> torch.Tensor:
+        if isinstance(img, torch.Tensor):
+            x = img
+            if x.dim() == 3 and x.shape[0] != 3 and x.shape[-1] == 3:
+                x = x.permute(2, 0, 1)
+        else:
+            import numpy as np
+
+            if hasattr(img, "convert"):
+                img = img.convert("RGB")
+            x = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1)
+        x = x.to(torch.float32)
+        if x.max() > 1.5:
+            x = x / 255.0
+        _, h, w = x.shape
+        s = n_px / min(h, w)
+        nh, nw = max(n_px, round(h * s)), max(n_px, round(w * s))
+        x = torch.nn.functional.interpolate(x[None], size=(nh, nw), mode="bicubic", align_corners=False,
+                                            antialias=True)[0].clamp(0, 1)
+        top, left = (nh - n_px) // 2, (nw - n_px) // 2
+        x = x[:, top:top + n_px, left:left + n_px]
+        return (x - mean) / std
+
+    return preprocess
+
+
+def load(name: str = "ViT-B/32", device: Union[str, torch.device] = "cuda", jit: bool = False,
+         download_root: Optional[str] = None, weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0):
+    """``clip.load`` signature.  No checkpoint can be fetched offline, so unless ``weights`` (a dict
+    in this repo's naming, see weights.py) is given, seeded synthetic weights of the named
+    architecture are generated -- the same tensors the golden fixtures were produced with."""
+    cfg = get_config(name)
+    if weights is None:
+        weights = make_clip_weights(cfg, seed=seed)
+    model = CLIP(cfg, weights, device)
+    return model, _preprocess_factory(cfg.vision.image_size)
+
+
+def tokenize(texts: Union[str, List[str], torch.Tensor, List[List[int]]], context_length: int = _CONTEXT,
+             truncate: bool = False) -> torch.Tensor:
+    """``clip.tokenize`` surface -> IntTensor[N, context_length].
+
+    The BPE vocabulary file ships with the ``clip`` package, which is absent offline (SURVEY.md 8f
+    row 4), so strings cannot be encoded here: pass token ids (one list per text, SOT..EOT, unpadded
+    or padded); they are zero-padded to ``context_length`` like the original.  Over-long inputs raise
+    RuntimeError exactly as ``clip.tokenize`` does unless ``truncate``."""
+    if isinstance(texts, str) or (isinstance(texts, (list, tuple)) and texts and isinstance(texts[0], str)):
+        raise RuntimeError("BPE vocabulary is not available offline; pass token ids instead of strings")
+    if isinstance(texts, torch.Tensor):
+        rows = texts.tolist() if texts.dim() == 2 else [texts.tolist()]
+    else:
+        rows = list(texts)
+        if rows and not isinstance(rows[0], (list, tuple)):
+            rows = [rows]
+    out = torch.zeros(len(rows), context_length, dtype=torch.int32)
+    for i, r in enumerate(rows):
+        r = list(r)
+        while r and r[-1] == 0:
+            r.pop()
+        if len(r) > context_length:
+            if not truncate:
+                raise RuntimeError(f"Input {i} is too long for context length {context_length}")
+            r = r[:context_length - 1] + [r[-1]]
+        out[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+    return out

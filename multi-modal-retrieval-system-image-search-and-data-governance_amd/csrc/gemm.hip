@@ -1,0 +1,174 @@
+// bf16 MFMA GEMM for the encoder's dense layers on gfx950:  C[M,N] = A[M,K] . W[N,K]^T  (+ epilogue)
+//
+// Both operands are K-contiguous (activations [tokens, in], torch Linear weights [out, in]) -- the
+// layout of every projection in the CLIP towers (q/k/v, out_proj, fc1, fc2, patch-embed as GEMM,
+// visual/text projection).
+//
+// Structure: 128x128x64 tile, 256 threads = 2x2 waves, each wave a 64x64 sub-tile as 4x4
+// v_mfma_f32_16x16x32_bf16; operands staged by global_load_lds (16 B/lane) into a double-buffered,
+// XOR-swizzled LDS image (swizzle applied on the SOURCE address so the image stays lane-linear);
+// fragments read with conflict-free ds_read_b128.  The MFMA is issued with the weight fragment as
+// the "A" operand so each lane ends up with 4 CONSECUTIVE output columns of one row: epilogues are
+// 8-byte (bf16) / 16-byte (fp32) stores and the bias is one float4 load.
+// Fused epilogues: +bias -> bf16 | +bias, QuickGELU -> bf16 | +bias, += fp32 residual | plain fp32.
+#include "mmr_common.h"
+
+namespace mmr {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int GEMM_THREADS = 256;
+constexpr int TILE_A_BYTES = BM * BK * 2;  // 16 KiB
+constexpr int TILE_B_BYTES = BN * BK * 2;
+constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_B_BYTES;
+
+enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_STORE_F32 = 3 };
+
+// byte offset of 16-B chunk `c` (0..7) of tile row `row` inside a [rows][64] bf16 tile image
+__device__ __forceinline__ int tile_off(int row, int c) {
+    return (row >> 3) * 1024 + (row & 7) * 128 + ((c ^ (row & 7)) << 4);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(
+    const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
+    const float *__restrict__ bias, void *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware block order: blocks that share an XCD (bid % 8) walk a contiguous range of tiles, so an
+    // A row-panel is re-read from that XCD's L2 by the N/BN blocks that need it.
+    const int gn = N / BN;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
+        bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    }
+    const int m0 = (bid / gn) * BM;
+    const int n0 = (bid % gn) * BN;
+
+    // ---- staging: each wave issues 4 + 4 global_load_lds per K-tile (1 KiB = 8 rows x 128 B each)
+    const int rr = lane >> 3;                 // row inside the 8-row block
+    const int sc = (lane & 7) ^ rr;           // source chunk that lands in LDS slot (lane & 7)
+    const bf16_t *a_src = A + (size_t)(m0 + wave * 32 + rr) * K + sc * 8;
+    const bf16_t *w_src = W + (size_t)(n0 + wave * 32 + rr) * K + sc * 8;
+    auto stage = [&](int kt, int buf) {
+        char *base = smem + buf * STAGE_BYTES;
+        const size_t ko = (size_t)kt * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int blk = wave * 4 + i;     // 8-row block index, 16 per tile
+            glds16(a_src + (size_t)i * 8 * K + ko, base + blk * 1024);
+            glds16(w_src + (size_t)i * 8 * K + ko, base + TILE_A_BYTES + blk * 1024);
+        }
+    };
+
+    f32x4 acc[4][4];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nkt = K / BK;
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+        const char *ta = smem + cur * STAGE_BYTES;
+        const char *tw = ta + TILE_A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8 *>(ta + tile_off(wm * 64 + i * 16 + fr, ks * 4 + fg));
+                wf[i] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(wn * 64 + i * 16 + fr, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+        }
+        __syncthreads();  // drains the prefetch (vmcnt(0)) and fences the buffer swap
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + {0,1,2,3}]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + fg * 4;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI != EPI_STORE_F32) b4 = *reinterpret_cast<const float4 *>(bias + n);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m = m0 + wm * 64 + mi * 16 + fr;
+            float v0 = acc[ni][mi][0] + b4.x, v1 = acc[ni][mi][1] + b4.y;
+            float v2 = acc[ni][mi][2] + b4.z, v3 = acc[ni][mi][3] + b4.w;
+            const size_t o = (size_t)m * N + n;
+            if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+                // QuickGELU x * sigmoid(1.702 x)  (transformers/activations.py:117-123)
+                v0 = v0 / (1.f + __expf(-1.702f * v0));
+                v1 = v1 / (1.f + __expf(-1.702f * v1));
+                v2 = v2 / (1.f + __expf(-1.702f * v2));
+                v3 = v3 / (1.f + __expf(-1.702f * v3));
+            }
+            if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v0, v1);
+                pk.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2 *>((bf16_t *)out + o) = pk;
+            } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                float4 *p = reinterpret_cast<float4 *>((float *)out + o);
+                float4 h = *p;
+                h.x += v0; h.y += v1; h.z += v2; h.w += v3;
+                *p = h;
+            } else {
+                *reinterpret_cast<float4 *>((float *)out + o) = make_float4(v0, v1, v2, v3);
+            }
+        }
+    }
+}
+
+// host launcher (internal): shapes are validated by the caller in tower.hip
+int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
+                hipStream_t st)
+{
+    if (M % BM || N % BN || K % BK || M <= 0 || N <= 0 || K <= 0) {
+        set_error("gemm: M=%d N=%d K=%d must be positive multiples of %d/%d/%d", M, N, K, BM, BN, BK);
+        return MMR_EINVAL;
+    }
+    const dim3 grid((M / BM) * (N / BN)), block(GEMM_THREADS);
+    const int lds = 2 * STAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI_BIAS_BF16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI_BIAS_GELU_BF16>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI_BIAS_RESID_F32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI_STORE_F32>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    switch (epi) {
+        case EPI_BIAS_BF16:
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_BF16>, grid, block, lds, st, A, W, M, N, K, bias, out); break;
+        case EPI_BIAS_GELU_BF16:
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_GELU_BF16>, grid, block, lds, st, A, W, M, N, K, bias, out); break;
+        case EPI_BIAS_RESID_F32:
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_RESID_F32>, grid, block, lds, st, A, W, M, N, K, bias, out); break;
+        default:
+            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_STORE_F32>, grid, block, lds, st, A, W, M, N, K, bias, out); break;
+    }
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+}  // namespace mmr

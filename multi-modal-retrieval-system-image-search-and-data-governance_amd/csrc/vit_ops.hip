@@ -1,0 +1,418 @@
+// Non-GEMM kernels of the CLIP towers for gfx950: patch gather, embeddings (+pre-LN), LayerNorm,
+// attention core, pooling LayerNorm, output cast / L2-normalise.
+// Arithmetic follows SURVEY.md Appendix A (transformers/models/clip/modeling_clip.py @5.15.0):
+//   embeddings :209-217,251-254   pre_layrnorm :642   attention :259-277   post/final LN :559,650
+// LayerNorm statistics, softmax and the residual stream are fp32; GEMM inputs are bf16.
+#include "mmr_common.h"
+
+#include <math.h>
+
+namespace mmr {
+
+// ---------------------------------------------------------------------------------------------
+// patches: pixels[B,3,S,S] -> Ap[B*G*G (padded rows untouched), Kpad] bf16, k = (c, ky, kx), zero pad
+// ---------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void im2col_kernel(const TIN *__restrict__ px, bf16_t *__restrict__ ap, int B,
+                                                     int S, int P, int G, int K, int Kpad)
+{
+    const int chunks_per_row = Kpad / 8;
+    const int64_t total = (int64_t)B * G * G * chunks_per_row;
+    for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total; id += (int64_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(id % chunks_per_row);
+        const int64_t row = id / chunks_per_row;
+        const int gx = (int)(row % G), gy = (int)((row / G) % G), b = (int)(row / ((int64_t)G * G));
+        float v[8];
+        const int k0 = ch * 8;
+        if ((P & 7) == 0 && k0 + 8 <= K) {
+            // 8 consecutive kx inside one (c, ky): a contiguous pixel run
+            const int c = k0 / (P * P), rem = k0 % (P * P), ky = rem / P, kx = rem % P;
+            const TIN *src = px + (((size_t)b * 3 + c) * S + (gy * P + ky)) * S + gx * P + kx;
+            if constexpr (sizeof(TIN) == 4) {
+                const float4 a = *reinterpret_cast<const float4 *>(src);
+                const float4 bq = *reinterpret_cast<const float4 *>(src + 4);
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = bq.x; v[5] = bq.y; v[6] = bq.z; v[7] = bq.w;
+            } else {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(src);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32((bf16_t)a[j]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                float x = 0.f;
+                if (k < K) {
+                    const int c = k / (P * P), rem = k % (P * P), ky = rem / P, kx = rem % P;
+                    const TIN *src = px + (((size_t)b * 3 + c) * S + (gy * P + ky)) * S + gx * P + kx;
+                    if constexpr (sizeof(TIN) == 4) x = *src; else x = bf16_to_f32(*(const bf16_t *)src);
+                }
+                v[j] = x;
+            }
+        }
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+        o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+        *reinterpret_cast<uint4 *>(ap + (size_t)row * Kpad + k0) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row LayerNorm helpers: one wave per row, VPL = d/64 values per lane held in registers
+// ---------------------------------------------------------------------------------------------
+template <int VPL>
+__device__ __forceinline__ void ln_row(float (&x)[VPL], const float *__restrict__ w, const float *__restrict__ b,
+                                       int lane, int d, float eps)
+{
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) s += x[j];
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { const float t = x[j] - mean; ss += t * t; }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int col = j * 64 + lane;
+        x[j] = (x[j] - mean) * rstd * w[col] + b[col];
+    }
+}
+
+// h[b*T + t] = LN_pre( (t == 0 ? cls : pe[b*G*G + t-1]) + pos[t] )        (fp32 residual stream)
+template <int VPL>
+__global__ __launch_bounds__(256) void embed_vision_kernel(const float *__restrict__ pe, const float *__restrict__ cls,
+                                                           const float *__restrict__ pos, const float *__restrict__ lw,
+                                                           const float *__restrict__ lb, float *__restrict__ h, int B,
+                                                           int T, int d, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)B * T) return;
+    const int t = (int)(row % T);
+    const int64_t b = row / T;
+    const float *src = t == 0 ? cls : pe + (size_t)(b * (T - 1) + t - 1) * d;
+    float x[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) x[j] = src[j * 64 + lane] + pos[(size_t)t * d + j * 64 + lane];
+    ln_row<VPL>(x, lw, lb, lane, d, eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) h[(size_t)row * d + j * 64 + lane] = x[j];
+}
+
+// h[n*T + t] = tok[ids[n,t]] + pos[t]
+template <int VPL>
+__global__ __launch_bounds__(256) void embed_text_kernel(const int32_t *__restrict__ ids, const bf16_t *__restrict__ tok,
+                                                         const float *__restrict__ pos, float *__restrict__ h, int Nb,
+                                                         int T, int d, int vocab)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)Nb * T) return;
+    const int t = (int)(row % T);
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // ids are validated on the host; clamp is a memory guard
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int col = j * 64 + lane;
+        h[(size_t)row * d + col] = bf16_to_f32(tok[(size_t)id * d + col]) + pos[(size_t)t * d + col];
+    }
+}
+
+// x_bf16[row] = LN(h[row])
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ h, const float *__restrict__ w,
+                                                        const float *__restrict__ b, bf16_t *__restrict__ x, int64_t rows,
+                                                        int d, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) v[j] = h[(size_t)row * d + j * 64 + lane];
+    ln_row<VPL>(v, w, b, lane, d, eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) x[(size_t)row * d + j * 64 + lane] = f32_to_bf16(v[j]);
+}
+
+// pooled rows: vision -> token 0 of each image; text -> first position of the largest id (EOT).
+// xc_bf16[n] = LN(h[n*T + pick])
+template <int VPL>
+__global__ __launch_bounds__(256) void pool_ln_kernel(const float *__restrict__ h, const int32_t *__restrict__ ids,
+                                                      const float *__restrict__ w, const float *__restrict__ b,
+                                                      bf16_t *__restrict__ xc, int Nb, int T, int d, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= Nb) return;
+    int pick = 0;
+    if (ids) {
+        int best = -2147483647 - 1, bpos = 0;
+        for (int t = lane; t < T; t += 64) {
+            const int v = ids[(size_t)n * T + t];
+            if (v > best) { best = v; bpos = t; }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const int ov = __shfl_xor(best, off, 64), op = __shfl_xor(bpos, off, 64);
+            if (ov > best || (ov == best && op < bpos)) { best = ov; bpos = op; }
+        }
+        pick = bpos;
+    }
+    const float *src = h + ((size_t)n * T + pick) * d;
+    float v[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) v[j] = src[j * 64 + lane];
+    ln_row<VPL>(v, w, b, lane, d, eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) xc[(size_t)n * d + j * 64 + lane] = f32_to_bf16(v[j]);
+}
+
+// out[n] = (normalize ? f / ||f|| : f) cast to the output dtype
+template <typename TOUT>
+__global__ __launch_bounds__(256) void finish_kernel(const float *__restrict__ feat, TOUT *__restrict__ out, int Nb, int E,
+                                                     int normalize)
+{
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= Nb) return;
+    const float *f = feat + (size_t)n * E;
+    float inv = 1.f;
+    if (normalize) {
+        float ss = 0.f;
+        for (int j = lane; j < E; j += 64) ss += f[j] * f[j];
+        inv = 1.0f / sqrtf(wave_sum(ss));
+    }
+    for (int j = lane; j < E; j += 64) {
+        const float v = f[j] * inv;
+        if constexpr (sizeof(TOUT) == 2) ((bf16_t *)out)[(size_t)n * E + j] = f32_to_bf16(v);
+        else ((float *)out)[(size_t)n * E + j] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// attention core: one workgroup per (image|text, head); head dim 64; T <= 16*NT (NT even)
+//   S^T = K.Q^T (keys on the MFMA row axis, so the softmax reduction over keys is mostly in-lane
+//   and the bf16 P tile is already the B operand of the P.V product), softmax fp32, O^T = V^T.P^T.
+// ---------------------------------------------------------------------------------------------
+template <int NT, bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o, int T,
+                                                        int d, float scale)
+{
+    constexpr int TPAD = NT * 16;
+    constexpr int VSTR = TPAD * 2 + 8;  // bytes per V^T row (+8 breaks the power-of-two stride)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *Ks = smem;                    // [TPAD][64] bf16, 16-B chunks XOR-swizzled by (row & 7)
+    char *Vt = smem + TPAD * 128;       // [64][VSTR]  V transposed: row = head dim, col = key
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = blockIdx.x, b = blockIdx.y;
+    const size_t ld = (size_t)3 * d;
+    const bf16_t *base = qkv + (size_t)b * T * ld + hd * 64;
+
+    for (int i = tid; i < TPAD * 8; i += 256) {
+        const int row = i >> 3, c = i & 7;
+        uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+        if (row < T) {
+            kk = *reinterpret_cast<const uint4 *>(base + (size_t)row * ld + d + c * 8);
+            vv = *reinterpret_cast<const uint4 *>(base + (size_t)row * ld + 2 * d + c * 8);
+        }
+        *reinterpret_cast<uint4 *>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kk;
+        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bf16_t val = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            *reinterpret_cast<bf16_t *>(Vt + (c * 8 + e) * VSTR + row * 2) = val;
+        }
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nqb = (T + 15) / 16;
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int qi = qb * 16 + fr;  // this lane's query (column of S^T)
+        bf16x8 qf[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[s] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (qi < T) qf[s] = *reinterpret_cast<const bf16x8 *>(base + (size_t)qi * ld + s * 32 + fg * 8);
+        }
+        f32x4 sc[NT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = jt * 16 + fr;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + row * 128 + (((s * 4 + fg) ^ (row & 7)) << 4));
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
+            }
+            sc[jt] = a;
+        }
+        // sc[jt][r] = S[query qi][key jt*16 + 4*fg + r]
+        float mx = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = jt * 16 + fg * 4 + r;
+                float v = sc[jt][r] * scale;
+                if (key >= T || (CAUSAL && key > qi)) v = -INFINITY;
+                sc[jt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[jt][r] - mx);
+                sc[jt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+
+        // P (bf16) as the B operand: k-slot (fg, jj) of k-step s2 <-> key 16*(2*s2 + (jj>>2)) + 4*fg + (jj&3)
+        f32x4 oacc[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < NT / 2; ++s2) {
+            union { bf16x8 v; uint32_t u[4]; } pf;
+            pf.u[0] = pack_bf16x2(sc[2 * s2][0] * inv, sc[2 * s2][1] * inv);
+            pf.u[1] = pack_bf16x2(sc[2 * s2][2] * inv, sc[2 * s2][3] * inv);
+            pf.u[2] = pack_bf16x2(sc[2 * s2 + 1][0] * inv, sc[2 * s2 + 1][1] * inv);
+            pf.u[3] = pack_bf16x2(sc[2 * s2 + 1][2] * inv, sc[2 * s2 + 1][3] * inv);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char *vr = Vt + (dt * 16 + fr) * VSTR + (32 * s2 + 4 * fg) * 2;
+                union { bf16x8 v; uint2 h[2]; } vf;
+                vf.h[0] = *reinterpret_cast<const uint2 *>(vr);
+                vf.h[1] = *reinterpret_cast<const uint2 *>(vr + 32);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, oacc[dt], 0, 0, 0);
+            }
+        }
+        // oacc[dt][r] = O[query qi][dim dt*16 + 4*fg + r]
+        if (qi < T) {
+            bf16_t *dst = o + ((size_t)b * T + qi) * d + hd * 64 + fg * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk;
+                pk.x = pack_bf16x2(oacc[dt][0], oacc[dt][1]);
+                pk.y = pack_bf16x2(oacc[dt][2], oacc[dt][3]);
+                *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers (internal; argument validation is done by tower.hip)
+// ---------------------------------------------------------------------------------------------
+#define MMR_VPL_SWITCH(d, ...)                                                     \
+    switch ((d) / 64) {                                                            \
+        case 2: { constexpr int VPL = 2; __VA_ARGS__; } break;                     \
+        case 8: { constexpr int VPL = 8; __VA_ARGS__; } break;                     \
+        case 12: { constexpr int VPL = 12; __VA_ARGS__; } break;                   \
+        case 16: { constexpr int VPL = 16; __VA_ARGS__; } break;                   \
+        default: set_error("width %d unsupported (128, 512, 768, 1024)", (d)); return MMR_ENOTSUP; \
+    }
+
+int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P, int G, int K, int Kpad, hipStream_t st)
+{
+    const int64_t total = (int64_t)B * G * G * (Kpad / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    if (dt == MMR_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)px, ap, B, S, P, G, K, Kpad);
+    else hipLaunchKernelGGL(im2col_kernel<bf16_t>, dim3(blocks), dim3(256), 0, st, (const bf16_t *)px, ap, B, S, P, G, K, Kpad);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h,
+                        int B, int T, int d, float eps, hipStream_t st)
+{
+    const dim3 grid((unsigned)(((int64_t)B * T + 3) / 4));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_vision_kernel<VPL>, grid, dim3(256), 0, st, pe, cls, pos, lw, lb, h, B, T, d, eps));
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab,
+                      hipStream_t st)
+{
+    const dim3 grid((unsigned)(((int64_t)Nb * T + 3) / 4));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_text_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, h, Nb, T, d, vocab));
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_layernorm(const float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps,
+                     hipStream_t st)
+{
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(layernorm_kernel<VPL>, grid, dim3(256), 0, st, h, w, b, x, rows, d, eps));
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const float *b, bf16_t *xc, int Nb, int T, int d,
+                   float eps, hipStream_t st)
+{
+    const dim3 grid((unsigned)((Nb + 3) / 4));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(pool_ln_kernel<VPL>, grid, dim3(256), 0, st, h, ids, w, b, xc, Nb, T, d, eps));
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_finish(const float *feat, void *out, mmr_dtype odt, int Nb, int E, int normalize, hipStream_t st)
+{
+    const dim3 grid((unsigned)((Nb + 3) / 4));
+    if (odt == MMR_BF16) hipLaunchKernelGGL(finish_kernel<bf16_t>, grid, dim3(256), 0, st, feat, (bf16_t *)out, Nb, E, normalize);
+    else hipLaunchKernelGGL(finish_kernel<float>, grid, dim3(256), 0, st, feat, (float *)out, Nb, E, normalize);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+template <int NT, bool CAUSAL>
+static int launch_attention_t(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, hipStream_t st)
+{
+    constexpr int TPAD = NT * 16;
+    constexpr int lds = TPAD * 128 + 64 * (TPAD * 2 + 8);
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<NT, CAUSAL>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((attention_kernel<NT, CAUSAL>), dim3(heads, Bn), dim3(256), lds, st, qkv, o, T, d, 0.125f);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, int causal, hipStream_t st)
+{
+    const int nt = (T + 31) / 32 * 2;
+    if (!causal) {
+        switch (nt) {
+            case 2: return launch_attention_t<2, false>(qkv, o, Bn, T, heads, d, st);
+            case 4: return launch_attention_t<4, false>(qkv, o, Bn, T, heads, d, st);
+            case 6: return launch_attention_t<6, false>(qkv, o, Bn, T, heads, d, st);
+            case 18: return launch_attention_t<18, false>(qkv, o, Bn, T, heads, d, st);
+            case 38: return launch_attention_t<38, false>(qkv, o, Bn, T, heads, d, st);
+        }
+    } else {
+        switch (nt) {
+            case 2: return launch_attention_t<2, true>(qkv, o, Bn, T, heads, d, st);
+            case 6: return launch_attention_t<6, true>(qkv, o, Bn, T, heads, d, st);
+        }
+    }
+    set_error("attention: %d tokens (%s) has no kernel instance", T, causal ? "causal" : "full");
+    return MMR_ENOTSUP;
+}
+
+}  // namespace mmr
