@@ -129,6 +129,24 @@ int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_dtype, int B
                       size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Launch profiler (measurement aid for bench.py): HIP event pairs around every kernel launch of a
+ * class, recorded on the launch stream.  Off by default.
+ * ---------------------------------------------------------------------------------------- */
+enum {
+    MMR_PROF_GEMM = 0,       /* gemm_bf16_kernel (all epilogues) */
+    MMR_PROF_ATTENTION = 1,  /* attention_kernel */
+    MMR_PROF_ROWWISE = 2,    /* LayerNorm / embedding / pooling / patch gather / output cast */
+    MMR_PROF_SCAN = 3,       /* scan_kernel (gallery stream, HBM-bound) */
+    MMR_PROF_FINALIZE = 4,   /* finalize_kernel (selection + exact re-rank) */
+    MMR_PROF_EXACT = 5,      /* exhaustive exact kernels */
+    MMR_PROF_CLASSES = 6
+};
+/* on != 0: reset and start recording up to max_launches launches; on == 0: stop. */
+int mmr_prof_enable(int on, int max_launches);
+/* Sum of event-pair durations (ms) and launch count of one class; synchronises those events. */
+int mmr_prof_read(int cls, double *total_ms, long long *launches, long long *dropped);
+
+/* ------------------------------------------------------------------------------------------
  * Kernel-level test hooks (used by tests/ to localise a parity failure; not part of the drop-in).
  * ---------------------------------------------------------------------------------------- */
 

@@ -35,4 +35,8 @@ def __getattr__(name):
 
         mod = importlib.import_module(f"{__name__}.{_LAZY[name]}")
         return getattr(mod, name)
+    if name in ("synth", "weights", "search", "clip", "config", "_lib", "gallery"):
+        import importlib
+
+        return importlib.import_module(f"{__name__}.{name}")
     raise AttributeError(name)

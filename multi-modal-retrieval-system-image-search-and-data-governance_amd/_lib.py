@@ -58,6 +58,11 @@ def lib():
     L.mmr_l2norm_rows.argtypes = [vp, i32, i64, i32, vp]
     L.mmr_topk_merge.restype = i32
     L.mmr_topk_merge.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
+    L.mmr_prof_enable.restype = i32
+    L.mmr_prof_enable.argtypes = [i32, i32]
+    L.mmr_prof_read.restype = i32
+    L.mmr_prof_read.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_longlong),
+                                ctypes.POINTER(ctypes.c_longlong)]
     if hasattr(L, "mmr_tower_create"):
         cfgp = ctypes.POINTER(TowerCfg)
         L.mmr_tower_weights_bytes.restype = sz
@@ -105,3 +110,21 @@ def stream_ptr(device=None) -> int:
 
 def ptr(t):
     return 0 if t is None else t.data_ptr()
+
+
+PROF_CLASSES = {"gemm": 0, "attention": 1, "rowwise": 2, "scan": 3, "finalize": 4, "exact": 5}
+
+
+def prof_enable(on: bool, max_launches: int = 65536):
+    check(lib().mmr_prof_enable(int(on), int(max_launches)))
+
+
+def prof_read():
+    """-> {class: (total_ms, launches)} for the launches recorded since prof_enable(True)."""
+    out = {}
+    for name, cls in PROF_CLASSES.items():
+        ms, n, dr = ctypes.c_double(), ctypes.c_longlong(), ctypes.c_longlong()
+        check(lib().mmr_prof_read(cls, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(dr)))
+        out[name] = (ms.value, n.value)
+    out["dropped"] = dr.value
+    return out

@@ -143,6 +143,7 @@ int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, 
         set_error("gemm: M=%d N=%d K=%d must be positive multiples of %d/%d/%d", M, N, K, BM, BN, BK);
         return MMR_EINVAL;
     }
+    ProfScope prof(MMR_PROF_GEMM, st);
     const dim3 grid((M / BM) * (N / BN)), block(GEMM_THREADS);
     const int lds = 2 * STAGE_BYTES;
     static bool attr_set = false;

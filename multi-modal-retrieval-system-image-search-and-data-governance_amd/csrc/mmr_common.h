@@ -54,6 +54,15 @@ __device__ __forceinline__ void wait_vmcnt() {
 // ------------------------------------------------------------------ host side
 void set_error(const char *fmt, ...);
 
+// Optional launch profiler (api_common.cpp): a ProfScope at a launch site records a HIP event pair
+// on the launch stream when mmr_prof_enable(1, n) is in force, and costs one branch otherwise.
+struct ProfScope {
+    ProfScope(int cls, hipStream_t st);
+    ~ProfScope();
+    long slot_;
+    hipStream_t st_;
+};
+
 #define MMR_CHECK_ARG(cond, ...)              \
     do {                                      \
         if (!(cond)) {                        \

@@ -714,6 +714,7 @@ template <int E>
 static int launch_scan(const bf16_t *q, const bf16_t *gal, int Qc, int64_t N, const SearchPlan &p, int qpad,
                        float *bmax, float *tmax, hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_SCAN, st);
     using C = ScanCfg<E>;
     const int lds = SCAN_NBUF * C::TILE_BYTES;
     static bool attr_set = false;
@@ -734,6 +735,7 @@ static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, c
                            const float *bmax, const float *tmax, float scale, float eps_coef, int32_t *idx,
                            float *score, double *dot64, int32_t *status, int32_t *flags, hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_FINALIZE, st);
     hipLaunchKernelGGL((finalize_kernel<T, PER>), dim3(Qc), dim3(FIN_THREADS), 0, st, q, gal, N, k, p.ks, p.ntiles,
                        p.tpt, p.ntasks, qpad, bmax, tmax, scale, eps_coef, idx, score, dot64, status, flags);
     MMR_CHECK_LAUNCH();
@@ -745,6 +747,7 @@ static int launch_exh(const T *q, const T *gal, int Q, int64_t N, int k, const S
                       const int32_t *flags, ExhEntry *partial, int32_t *idx, float *score, double *dot64,
                       hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_EXACT, st);
     hipLaunchKernelGGL((exh_scan_kernel<T, PER>), dim3(p.nslab, Q), dim3(256), 0, st, q, gal, N, k, p.nslab,
                        p.rows_per_slab, flags, partial);
     MMR_CHECK_LAUNCH();

@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
 
 int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P, int G, int K, int Kpad, hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_ROWWISE, st);
     const int64_t total = (int64_t)B * G * G * (Kpad / 8);
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     if (dt == MMR_F32) hipLaunchKernelGGL(im2col_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float *)px, ap, B, S, P, G, K, Kpad);
@@ -336,6 +337,7 @@ int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P,
 int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h,
                         int B, int T, int d, float eps, hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)(((int64_t)B * T + 3) / 4));
     MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_vision_kernel<VPL>, grid, dim3(256), 0, st, pe, cls, pos, lw, lb, h, B, T, d, eps));
     MMR_CHECK_LAUNCH();
@@ -345,6 +347,7 @@ int launch_embed_vision(const float *pe, const float *cls, const float *pos, con
 int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab,
                       hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)(((int64_t)Nb * T + 3) / 4));
     MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_text_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, h, Nb, T, d, vocab));
     MMR_CHECK_LAUNCH();
@@ -354,6 +357,7 @@ int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, f
 int launch_layernorm(const float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps,
                      hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)((rows + 3) / 4));
     MMR_VPL_SWITCH(d, hipLaunchKernelGGL(layernorm_kernel<VPL>, grid, dim3(256), 0, st, h, w, b, x, rows, d, eps));
     MMR_CHECK_LAUNCH();
@@ -363,6 +367,7 @@ int launch_layernorm(const float *h, const float *w, const float *b, bf16_t *x, 
 int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const float *b, bf16_t *xc, int Nb, int T, int d,
                    float eps, hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)((Nb + 3) / 4));
     MMR_VPL_SWITCH(d, hipLaunchKernelGGL(pool_ln_kernel<VPL>, grid, dim3(256), 0, st, h, ids, w, b, xc, Nb, T, d, eps));
     MMR_CHECK_LAUNCH();
@@ -371,6 +376,7 @@ int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const flo
 
 int launch_finish(const float *feat, void *out, mmr_dtype odt, int Nb, int E, int normalize, hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)((Nb + 3) / 4));
     if (odt == MMR_BF16) hipLaunchKernelGGL(finish_kernel<bf16_t>, grid, dim3(256), 0, st, feat, (bf16_t *)out, Nb, E, normalize);
     else hipLaunchKernelGGL(finish_kernel<float>, grid, dim3(256), 0, st, feat, (float *)out, Nb, E, normalize);
@@ -381,6 +387,7 @@ int launch_finish(const float *feat, void *out, mmr_dtype odt, int Nb, int E, in
 template <int NT, bool CAUSAL>
 static int launch_attention_t(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, hipStream_t st)
 {
+    ProfScope prof(MMR_PROF_ATTENTION, st);
     constexpr int TPAD = NT * 16;
     constexpr int lds = TPAD * 128 + 64 * (TPAD * 2 + 8);
     static bool attr_set = false;
