@@ -202,8 +202,9 @@ class ShardedGalleryIndex:
         # one packed message per rank: [Q,k,2] int64 = (global id, fp64 dot bits)
         packed = torch.stack([gidx, ldot.view(torch.int64)], dim=-1).contiguous()
         if self.world > 1:
-            gathered = torch.empty((self.world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-            self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
+            parts = [torch.empty_like(packed) for _ in range(self.world)]
+            self.dist.all_gather(parts, packed, group=self.group)     # the one collective of the search path
+            gathered = torch.stack(parts)
         else:
             gathered = packed.unsqueeze(0)
         idx_parts = gathered[..., 0].contiguous()

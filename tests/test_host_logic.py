@@ -1,0 +1,174 @@
+"""CPU: host-side logic, the C-ABI surface (no compute launches), and the N>1 search path on gloo."""
+import ctypes
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import mmr_amd
+from mmr_amd import config, synth, weights
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    from mmr_amd import _lib
+
+    if not os.path.exists(_lib.LIB_PATH):
+        ge.build()
+    return _lib
+
+
+def test_library_exports_every_header_symbol(lib):
+    L = lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "mmr.h")).read()
+    names = sorted(set(re.findall(r"\b(mmr_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 18
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    assert L.mmr_version() == 1
+
+
+def test_argument_validation_happens_before_any_launch(lib):
+    L = lib.lib()
+    # every one of these returns on the host, so they are safe without a GPU
+    rc = L.mmr_cosine_topk(0, 0, 1, 4, 100, 512, 0, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 0)
+    assert rc == -22 and b"k=0" in L.mmr_last_error()
+    rc = L.mmr_cosine_topk(0, 0, 1, 4, 100, 512, 10, -1.0, 1.0, 0, 0, 0, 0, 0, 0, 0)
+    assert rc == -22 and b"scale" in L.mmr_last_error()
+    rc = L.mmr_cosine_topk(0, 0, 1, 4, 100, 100, 10, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 0)
+    assert rc == -95 and b"E=100" in L.mmr_last_error()
+    rc = L.mmr_cosine_topk(0, 0, 7, 4, 100, 512, 10, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 0)
+    assert rc == -22 and b"dtype" in L.mmr_last_error()
+    rc = L.mmr_cosine_topk(16, 16, 1, 4, 100, 512, 10, 1.0, 1.0, 16, 16, 0, 0, 16, 8, 0)
+    assert rc == -28 and b"workspace" in L.mmr_last_error()
+    assert L.mmr_cosine_topk(0, 0, 1, 0, 100, 512, 10, 1.0, 1.0, 0, 0, 0, 0, 0, 0, 0) == 0      # Q == 0: nothing to do
+    assert L.mmr_l2norm_rows(0, 1, 0, 512, 0) == 0
+    assert L.mmr_topk_merge(0, 0, 0, 1, 1, 1.0, 0, 0, 0, 0) == -22
+    need = L.mmr_search_workspace_bytes(1_000_000, 512, 256, 10)
+    assert 30e6 < need < 80e6
+
+
+def test_tower_layout(lib):
+    from mmr_amd.clip import _tower_cfg_struct
+    L = lib.lib()
+    ccfg = mmr_amd.get_config("ViT-B/32")
+    c = _tower_cfg_struct(ccfg.vision)
+    total = L.mmr_tower_weights_bytes(ctypes.byref(c))
+    n_matrix = 768 * 3072 + 12 * (3 * 768 * 768 + 768 * 768 + 2 * 768 * 3072) + 512 * 768
+    assert n_matrix * 2 < total < n_matrix * 2 * 1.02            # bf16 matrices + small fp32 vectors
+    off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+    seen = []
+    for layer in range(12):
+        for p in range(lib.P_LN1_W, lib.P_FC2_B + 1):
+            assert L.mmr_tower_param_span(ctypes.byref(c), p, layer, ctypes.byref(off), ctypes.byref(nb)) == 0
+            assert off.value % 256 == 0 and off.value + nb.value <= total
+            seen.append((off.value, nb.value))
+    seen.sort()
+    assert all(a[0] + a[1] <= b[0] for a, b in zip(seen, seen[1:])), "tensor spans overlap"
+    assert L.mmr_tower_param_span(ctypes.byref(c), lib.P_TOK_EMB, 0, ctypes.byref(off), ctypes.byref(nb)) == -22
+    assert L.mmr_tower_param_span(ctypes.byref(c), lib.P_QKV_W, 12, ctypes.byref(off), ctypes.byref(nb)) == -22
+    bad = _tower_cfg_struct(ccfg.vision)
+    bad.heads = 8
+    assert L.mmr_tower_weights_bytes(ctypes.byref(bad)) == 0
+    t = _tower_cfg_struct(ccfg.text)
+    assert L.mmr_tower_param_span(ctypes.byref(t), lib.P_TOK_EMB, 0, ctypes.byref(off), ctypes.byref(nb)) == 0
+    assert nb.value == 49408 * 512 * 2
+
+
+def test_configs_and_weights():
+    assert mmr_amd.available_models() == ["ViT-B/32", "ViT-L/14", "ViT-L/14@336px"]
+    assert config.get_config("openai/clip-vit-large-patch14").name == "ViT-L/14"
+    with pytest.raises(RuntimeError):
+        config.get_config("RN50")
+    c = config.get_config("ViT-L/14@336px")
+    assert c.vision.tokens == 577 and c.vision.patch_k == 588 and c.vision.patch_k_pad == 640
+    w1 = weights.make_vision_weights(config.get_config("tiny-test").vision, seed=0)
+    w2 = weights.make_vision_weights(config.get_config("tiny-test").vision, seed=0)
+    w3 = weights.make_vision_weights(config.get_config("tiny-test").vision, seed=1)
+    assert all(torch.equal(w1[k], w2[k]) for k in w1)                      # deterministic
+    assert not torch.equal(w1["v.proj"], w3["v.proj"])
+    assert all(torch.equal(v, v.bfloat16().float()) for v in w1.values())  # bf16-representable
+
+
+def test_tokenize_surface():
+    from mmr_amd.clip import tokenize
+    ids = synth.synth_token_ids(4, 77, 49408, seed=1)
+    out = tokenize(ids)
+    assert out.shape == (4, 77) and out.dtype == torch.int32 and torch.equal(out, ids)
+    short = tokenize([[49406, 320, 1125, 49407]])
+    assert short.shape == (1, 77) and short[0, :4].tolist() == [49406, 320, 1125, 49407] and short[0, 4:].sum() == 0
+    with pytest.raises(RuntimeError):
+        tokenize(["a diagram", "a dog"])                 # no BPE vocabulary offline
+    with pytest.raises(RuntimeError):
+        tokenize([list(range(1, 90))])                   # too long, like clip.tokenize
+    t = tokenize([list(range(1, 90))], truncate=True)
+    assert t.shape == (1, 77) and t[0, -1] == 89
+
+
+def test_no_gpu_means_loud_failure():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mmr_amd import search
+    with pytest.raises(RuntimeError):
+        mmr_amd.load("tiny-test", device="cpu")
+    with pytest.raises(RuntimeError):
+        search.cosine_topk(torch.randn(1, 512), torch.randn(8, 512), 1)
+
+
+# ------------------------------------------------------------------ N > 1 on gloo (CPU)
+def _sharded_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from mmr_amd import search
+    from oracle import search_ref
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gal = synth.synth_unit_rows(3001, 512, seed=31).bfloat16()
+        bounds = [0, 1200, 3001]                                   # ragged shards
+        local = gal[bounds[rank]:bounds[rank + 1]]
+        queries = synth.synth_unit_rows(6, 512, seed=32).bfloat16()
+
+        def local_search(qs, g, k):                                # the oracle stands in for the HIP kernels
+            i, _, d = search_ref.cosine_topk(qs, g, k)
+            return torch.from_numpy(i), torch.from_numpy(d)
+
+        def merge(idx_parts, dot_parts, scale):
+            i, s, d = search_ref.topk_merge(idx_parts.numpy(), dot_parts.numpy(), scale)
+            return torch.from_numpy(s), torch.from_numpy(i), torch.from_numpy(d)
+
+        index = search.ShardedGalleryIndex(local, local_search=local_search, merge=merge)
+        assert index.total_rows == 3001 and index.offset == bounds[rank]
+        score, idx = index.search(queries, 10, 100.0)
+        oi, os_, _ = search_ref.cosine_topk(queries, gal, 10, 100.0)
+        ok = bool(np.array_equal(idx.numpy(), oi) and np.array_equal(score.numpy(), os_))
+        # k larger than the smaller shard: empty slots (-1) must not leak into the merge
+        score2, idx2 = index.search(queries, 40, 1.0)
+        oi2, _, _ = search_ref.cosine_topk(queries, gal, 40, 1.0)
+        ok = ok and bool(np.array_equal(idx2.numpy(), oi2))
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29000 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+    results = sorted(q.get(timeout=5) for _ in range(2))
+    assert results == [(0, True), (1, True)]
+    assert all(p.exitcode == 0 for p in procs)
