@@ -105,6 +105,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on
+    # stdout, so everything else is routed to stderr and the JSON goes to the saved descriptor.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -116,8 +122,12 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     import torch.distributed as dist
-    if world > 1:
+    # under torch.distributed.run (RANK set) always build the process group, also for one rank, so
+    # the collective path can be rehearsed on a single GPU; plain `python bench.py` stays group-free
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import mmr_amd
@@ -136,7 +146,7 @@ def main():
         x = torch.randn(e - s, EMBED, generator=g, device=dev)
         gal[s:e] = (x / x.norm(dim=-1, keepdim=True)).bfloat16()
     queries = synth.synth_unit_rows(QUERIES, EMBED, seed=4).bfloat16().to(dev)   # replicated on every rank
-    index = search.ShardedGalleryIndex(gal, group=None) if world > 1 else search.GalleryIndex(gal)
+    index = search.ShardedGalleryIndex(gal, group=None) if use_dist else search.GalleryIndex(gal)
 
     def step(ev=None):
         if ev:
@@ -151,7 +161,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -177,7 +187,7 @@ def main():
     prof = _lib.prof_read()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -244,8 +254,9 @@ def main():
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": host_cores(), "kind": "port",
                                         "sample": f"failed: {ex!r}"}
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

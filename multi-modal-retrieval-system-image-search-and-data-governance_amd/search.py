@@ -174,14 +174,15 @@ class ShardedGalleryIndex:
 
         self.dist = dist
         self.group = group
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.use_dist = dist.is_available() and dist.is_initialized()   # collectives run even for a 1-rank group
+        self.world = dist.get_world_size(group) if self.use_dist else 1
+        self.rank = dist.get_rank(group) if self.use_dist else 0
         self.local = local_gallery
         self._index = GalleryIndex(local_gallery, norm_bound) if local_search is None else None
         self._local_search = local_search
         self._merge = merge or merge_topk
         n_local = torch.tensor([local_gallery.shape[0]], dtype=torch.int64, device=local_gallery.device)
-        if self.world > 1:
+        if self.use_dist:
             counts = [torch.zeros_like(n_local) for _ in range(self.world)]
             dist.all_gather(counts, n_local, group=group)
             counts = torch.cat(counts)
@@ -201,7 +202,7 @@ class ShardedGalleryIndex:
         gidx = torch.where(lidx >= 0, lidx.to(torch.int64) + self.offset, lidx.to(torch.int64))
         # one packed message per rank: [Q,k,2] int64 = (global id, fp64 dot bits)
         packed = torch.stack([gidx, ldot.view(torch.int64)], dim=-1).contiguous()
-        if self.world > 1:
+        if self.use_dist:
             parts = [torch.empty_like(packed) for _ in range(self.world)]
             self.dist.all_gather(parts, packed, group=self.group)     # the one collective of the search path
             gathered = torch.stack(parts)
