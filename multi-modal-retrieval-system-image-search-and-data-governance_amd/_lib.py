@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libmmr_hip.so")
+LIB_PATH = os.environ.get("MMR_LIB") or os.path.join(_HERE, "csrc", "libmmr_hip.so")   # MMR_LIB: A/B builds
 
 MMR_F32, MMR_BF16 = 0, 1
 _ERRNAMES = {-5: "EIO", -22: "EINVAL", -28: "ENOSPC", -95: "ENOTSUP"}

@@ -15,7 +15,7 @@ SOURCES = ["api_common.cpp", "search.hip", "gemm.hip", "vit_ops.hip", "tower.hip
 LIB = os.path.join(HERE, "libmmr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
-         "-Wno-unused-result", "-Wno-unused-value"]
+         "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("MMR_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _obj(src):

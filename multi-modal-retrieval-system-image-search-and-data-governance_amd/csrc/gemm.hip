@@ -13,6 +13,8 @@
 // Fused epilogues: +bias -> bf16 | +bias, QuickGELU -> bf16 | +bias, += fp32 residual | plain fp32.
 #include "mmr_common.h"
 
+#include <stdlib.h>
+
 namespace mmr {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -29,7 +31,10 @@ __device__ __forceinline__ int tile_off(int row, int c) {
 }
 
 template <int EPI>
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(
+#ifndef MMR_GEMM_MINWAVES
+#define MMR_GEMM_MINWAVES 1
+#endif
+__global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
     const float *__restrict__ bias, void *__restrict__ out)
 {
@@ -89,11 +94,17 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(
                 af[i] = *reinterpret_cast<const bf16x8 *>(ta + tile_off(wm * 64 + i * 16 + fr, ks * 4 + fg));
                 wf[i] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(wn * 64 + i * 16 + fr, ks * 4 + fg));
             }
+#ifdef MMR_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
+#ifdef MMR_GEMM_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         }
         __syncthreads();  // drains the prefetch (vmcnt(0)) and fences the buffer swap
         cur ^= 1;
@@ -135,6 +146,194 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 tile, 8 waves (2 along M x 4 along N), each wave a 128x64 sub-tile = 32 accumulators.
+// Operand fetch per CU, not MFMA issue, bounds the 128^2 kernel on these shapes (both structures
+// settle near the same ~17 B/clk/CU of L2->LDS traffic), so the lever is FLOPs per fetched byte:
+// this tile does 2x the work per byte.  Pipeline: every K-tile is 4 phases of 16 MFMAs (one
+// 64x32 quadrant of the wave's sub-tile over K=64); each phase reads its fragments, stages one
+// 16 KiB half-tile (A rows 0-127 / 128-255, W rows 0-127 / 128-255) of a FUTURE K-tile by
+// global_load_lds (LOAD segment), then runs its MFMA cluster (COMPUTE segment); segments are
+// separated by raw s_barriers and the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD)
+// run staggered by one segment, so LDS reads of one hide under the MFMAs of the other.  Half-tiles
+// are staged in the rotating order W0,W1,A0,A1 so each lands 3-6 phases before its first read; the
+// only wait on the load queue is a counted vmcnt(4) once per K-tile (never 0 inside the loop), two
+// barriers before the first read of the data it retires.
+// ---------------------------------------------------------------------------------------------
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int GEMM2_THREADS = 512;
+constexpr int HALF_BYTES = 128 * BK * 2;            // 16 KiB: 128 rows x 64 bf16
+constexpr int STAGE2_BYTES = 4 * HALF_BYTES;        // A0 A1 W0 W1
+constexpr int GEMM2_LDS = 2 * STAGE2_BYTES;         // 128 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
+    const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
+    const float *__restrict__ bias, void *__restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int gn = N / BN2;
+    const int nblk = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
+        bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    }
+    const int m0 = (bid / gn) * BM2;
+    const int n0 = (bid % gn) * BN2;
+
+    // ---- staging: a half-tile is 16 blocks of 8 rows (1 KiB); wave w issues blocks 2w, 2w+1
+    const int rr = lane >> 3;
+    const int sc = (lane & 7) ^ rr;
+    const bf16_t *a_src = A + (size_t)(m0 + wave * 16 + rr) * K + sc * 8;   // + half*128 rows, + i*8 rows, + kt*64
+    const bf16_t *w_src = W + (size_t)(n0 + wave * 16 + rr) * K + sc * 8;
+    const int nkt = K / BK;
+    // kind: 0 = W0, 1 = W1, 2 = A0, 3 = A1  (the rotating stream order)
+    auto stage = [&](int kt, int kind) {
+        if (kt >= nkt) return;
+        const int half = kind & 1;
+        const bool isA = kind >= 2;
+        const bf16_t *src = (isA ? a_src : w_src) + (size_t)half * 128 * K + (size_t)kt * BK;
+        char *dst = smem + (kt & 1) * STAGE2_BYTES + ((isA ? 0 : 2) + half) * HALF_BYTES + wave * 2048;
+        glds16(src, dst);
+        glds16(src + (size_t)8 * K, dst + 1024);
+    };
+
+    f32x4 acc[4][8];  // [ni][mi]
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    // per-lane fragment byte offsets inside a half-tile image (rows of this wave)
+    const int a_half = wr;                        // A half-tile this wave reads
+    const int w_half = wc >> 1;                   // W half-tile this wave reads
+    const int w_row0 = (wc & 1) * 64;
+
+    // prologue: stream elements 0..5 = W0,W1,A0,A1 of tile 0 and W0,W1 of tile 1
+    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
+    if (nkt > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    // Stagger: waves 4-7 (wr == 1, the SIMD partners of waves 0-3) run one segment behind, so on every
+    // SIMD one wave is in a LOAD segment (ds_read + global_load_lds) while its partner is in a COMPUTE
+    // segment (16 MFMAs).  Every wave executes the same number of barriers (compensated after the loop).
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+
+    bf16x8 af[4][2], wf[2][2][2];   // af[mi][ks];  wf[nh][ni][ks]
+#define MMR_LOAD_DONE()  do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+    for (int kt = 0; kt < nkt; ++kt) {
+        const char *sb = smem + (kt & 1) * STAGE2_BYTES;
+        const char *ta = sb + a_half * HALF_BYTES;
+        const char *tw = sb + (2 + w_half) * HALF_BYTES;
+
+        auto read_w = [&](int nh) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    wf[nh][ni][ks] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(w_row0 + nh * 32 + ni * 16 + fr, ks * 4 + fg));
+        };
+        auto read_a = [&](int mh) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    af[mi][ks] = *reinterpret_cast<const bf16x8 *>(ta + tile_off(mh * 64 + mi * 16 + fr, ks * 4 + fg));
+        };
+        auto mma = [&](int mh, int nh) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+                        acc[nh * 2 + ni][mh * 4 + mi] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][ni][ks], af[mi][ks], acc[nh * 2 + ni][mh * 4 + mi], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        };
+
+        // phase 0: quadrant (m-half 0, n-half 0); stage A0 of tile kt+1
+        read_w(0); read_a(0);
+        stage(kt + 1, 2);
+        MMR_LOAD_DONE();
+        mma(0, 0);
+        // phase 1: quadrant (0, 1); stage A1 of tile kt+1
+        read_w(1);
+        stage(kt + 1, 3);
+        MMR_LOAD_DONE();
+        mma(0, 1);
+        // phase 2: quadrant (1, 1); stage W0 of tile kt+2 (W of tile kt was last read in phase 1)
+        read_a(1);
+        stage(kt + 2, 0);
+        MMR_LOAD_DONE();
+        mma(1, 1);
+        // phase 3: quadrant (1, 0); stage W1 of tile kt+2; retire tile kt+1's four half-tiles (the
+        // youngest of them was staged in phase 1) two barriers before the other group's first read
+        stage(kt + 2, 1);
+        if (kt + 2 < nkt) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        MMR_LOAD_DONE();
+        mma(1, 0);
+    }
+#undef MMR_LOAD_DONE
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + {0,1,2,3}]
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wc * 64 + ni * 16 + fg * 4;
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (EPI != EPI_STORE_F32) b4 = *reinterpret_cast<const float4 *>(bias + n);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + wr * 128 + mi * 16 + fr;
+            float v0 = acc[ni][mi][0] + b4.x, v1 = acc[ni][mi][1] + b4.y;
+            float v2 = acc[ni][mi][2] + b4.z, v3 = acc[ni][mi][3] + b4.w;
+            const size_t o = (size_t)m * N + n;
+            if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+                v0 = v0 / (1.f + __expf(-1.702f * v0));
+                v1 = v1 / (1.f + __expf(-1.702f * v1));
+                v2 = v2 / (1.f + __expf(-1.702f * v2));
+                v3 = v3 / (1.f + __expf(-1.702f * v3));
+            }
+            if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v0, v1);
+                pk.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2 *>((bf16_t *)out + o) = pk;
+            } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                float4 *p = reinterpret_cast<float4 *>((float *)out + o);
+                float4 h = *p;
+                h.x += v0; h.y += v1; h.z += v2; h.w += v3;
+                *p = h;
+            } else {
+                *reinterpret_cast<float4 *>((float *)out + o) = make_float4(v0, v1, v2, v3);
+            }
+        }
+    }
+}
+
+template <int EPI>
+static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, dim3((M / BM2) * (N / BN2)), dim3(GEMM2_THREADS), GEMM2_LDS, st, A, W, M, N,
+                       K, bias, out);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
 // host launcher (internal): shapes are validated by the caller in tower.hip
 int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
                 hipStream_t st)
@@ -144,6 +343,18 @@ int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, 
         return MMR_EINVAL;
     }
     ProfScope prof(MMR_PROF_GEMM, st);
+    static const int force = getenv("MMR_GEMM_TILE") ? atoi(getenv("MMR_GEMM_TILE")) : 0;   // 128 / 256: A/B aid
+    const bool fits256 = (M % BM2 == 0) && (N % BN2 == 0);
+    // the 256^2 kernel runs one workgroup per CU: it needs enough tiles to occupy the chip
+    const bool big = (long long)(M / BM2) * (N / BN2) >= 128;
+    if (fits256 && (force == 256 || (force == 0 && big))) {
+        switch (epi) {
+            case EPI_BIAS_BF16: return launch_gemm256<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
+            case EPI_BIAS_GELU_BF16: return launch_gemm256<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);
+            case EPI_BIAS_RESID_F32: return launch_gemm256<EPI_BIAS_RESID_F32>(A, W, M, N, K, bias, out, st);
+            default: return launch_gemm256<EPI_STORE_F32>(A, W, M, N, K, bias, out, st);
+        }
+    }
     const dim3 grid((M / BM) * (N / BN)), block(GEMM_THREADS);
     const int lds = 2 * STAGE_BYTES;
     static bool attr_set = false;

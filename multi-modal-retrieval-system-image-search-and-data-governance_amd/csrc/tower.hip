@@ -161,7 +161,7 @@ WsPlan plan_ws(const mmr_tower_cfg &c, int B)
 {
     WsPlan p{};
     p.M = B * c.tokens;
-    p.Mpad = round_up(p.M, 128);
+    p.Mpad = round_up(p.M, p.M >= 4096 ? 256 : 128);   // large batches: row count fits the 256x256 GEMM tile
     p.Bpad = round_up(B, 128);
     const size_t d = c.width;
     const size_t wide = (size_t)(c.mlp > 3 * c.width ? c.mlp : 3 * c.width);
@@ -170,7 +170,7 @@ WsPlan plan_ws(const mmr_tower_cfg &c, int B)
     auto put = [&](size_t &o, size_t bytes) { o = off; off += align_up(bytes, 256); };
     if (c.kind == 0) {
         p.Mp = B * (c.tokens - 1);
-        p.Mp_pad = round_up(p.Mp, 128);
+        p.Mp_pad = round_up(p.Mp, p.Mp >= 4096 ? 256 : 128);
         const size_t ap = (size_t)p.Mp_pad * patch_kpad(c) * 2;
         if (ap > big) big = ap;
     }

@@ -29,7 +29,9 @@ def _cos(a, b):
 
 
 # ------------------------------------------------------------------ kernel-level
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (1280, 2304, 768), (384, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (1280, 2304, 768), (384, 768, 3072),
+                                   (256, 256, 64), (512, 256, 128), (256, 768, 192), (4096, 1024, 256),
+                                   (12800, 768, 768)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3])
 def test_gemm_epilogues(L, device, M, N, K, epi):
     g = torch.Generator().manual_seed(M + N + K + epi)
