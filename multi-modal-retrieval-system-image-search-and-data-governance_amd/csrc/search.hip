@@ -28,7 +28,11 @@
 namespace mmr {
 
 constexpr int TILE_ROWS = 32;
-constexpr int SCAN_NBUF = 3;
+#ifndef MMR_SCAN_NBUF
+#define MMR_SCAN_NBUF 3
+#endif
+constexpr int SCAN_NBUF = MMR_SCAN_NBUF;
+static_assert(SCAN_NBUF == 3 || SCAN_NBUF == 4, "wait counts below assume a prefetch distance of 2 or 3 tiles");
 constexpr int MAX_TPT = 64;                 // tiles per task
 constexpr int KS_MAX = 32;                  // candidate tiles kept per query
 constexpr int K_MAX = 64;                   // largest k (exhaustive path)
@@ -111,32 +115,47 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
     float pend = -INFINITY;
     int pend_tile = -1;
 
-    stage(t0, 0);
-    if (t0 + 1 < t1) stage(t0 + 1, 1);
+    // prefetch distance PD = NBUF - 1 tiles
+    constexpr int PD = SCAN_NBUF - 1;
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+        if (t0 + i < t1) stage(t0 + i, i);
     int cur = 0;
 
     for (int t = t0; t < t1; ++t) {
-        // this wave's loads of tile t have landed (tile t+1 may stay in flight) ...
-        if (t + 1 < t1) wait_vmcnt<C::LPW>(); else wait_vmcnt<0>();
+        // this wave's loads of tile t have landed (younger tiles may stay in flight) ...
+        const int younger = min(PD - 1, t1 - 1 - t);
+        if (younger >= 2) wait_vmcnt<2 * C::LPW>();
+        else if (younger == 1) wait_vmcnt<C::LPW>();
+        else wait_vmcnt<0>();
         // ... and after the barrier so have every other wave's.
         __builtin_amdgcn_s_barrier();
 
         if (compute && pend_tile >= 0 && h == 0) bmax[(size_t)pend_tile * qpad + wave * 32 + c] = pend;
 
-        int nxt = cur + 2; nxt = nxt >= SCAN_NBUF ? nxt - SCAN_NBUF : nxt;
-        if (t + 2 < t1) stage(t + 2, nxt);  // overwrites tile t-1's buffer: all waves are past it
+        int nxt = cur + PD; nxt = nxt >= SCAN_NBUF ? nxt - SCAN_NBUF : nxt;
+        if (t + PD < t1) stage(t + PD, nxt);  // overwrites tile t-1's buffer: all waves are past it
 
         if (compute) {
             const char *tb = smem + cur * C::TILE_BYTES + rowoff;
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#pragma unroll
-            for (int s = 0; s < C::KSTEPS; ++s) {
+            // A fragments run PF k-steps ahead of the MFMA that consumes them, so LDS latency hides
+            // behind the (dependent) MFMA chain instead of being paid every other step.
+            constexpr int PF = 4;
+            auto afrag = [&](int s) {
                 const int chunk = 2 * s + h;
                 const int pos = (chunk & ~15) | ((chunk ^ c) & 15);
-                bf16x8 a = *reinterpret_cast<const bf16x8 *>(tb + pos * 16);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bq[s], acc, 0, 0, 0);
+                return *reinterpret_cast<const bf16x8 *>(tb + pos * 16);
+            };
+            bf16x8 a[PF];
+#pragma unroll
+            for (int s = 0; s < PF; ++s) a[s] = afrag(s);
+#pragma unroll
+            for (int s = 0; s < C::KSTEPS; ++s) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % PF], bq[s], acc, 0, 0, 0);
+                if (s + PF < C::KSTEPS) a[s % PF] = afrag(s + PF);
             }
             // acc[i] = dot(query c, tile row (i&3) + 8*(i>>2) + 4*h)
             float m = -INFINITY;
@@ -302,20 +321,15 @@ __device__ __forceinline__ void wave_rounds(V (&v)[R], int32_t (&key)[R], int ro
     }
 }
 
-// Workgroup selection over n candidates.  get(i, v, key) -> bool valid; keys unique, < KEY_NONE.
-// n <= 4096: candidates live in registers, each wave extracts its own `rounds` winners, wave 0
-// merges the 4 lists (2 barriers in all).  Larger n: one global sweep per round (slow, rare).
-// Results land in out_v/out_k (shared memory) and are visible to every thread on return.
-template <typename V, typename F>
-__device__ void wg_select(int n, int rounds, F get, V *out_v, int32_t *out_k, SelScratch<V> *sc) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = FIN_THREADS / 64;
-    if (n <= SEL_FAST_MAX) {
-        V v[SEL_R];
-        int32_t key[SEL_R];
+template <typename V, int R, typename F>
+__device__ __forceinline__ void wave_select_single(int n, int rounds, F get, V *out_v, int32_t *out_k) {
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        V v[R];
+        int32_t key[R];
 #pragma unroll
-        for (int j = 0; j < SEL_R; ++j) {
-            const int i = tid + j * FIN_THREADS;
+        for (int j = 0; j < R; ++j) {
+            const int i = tid + j * 64;
             V x = (V)-INFINITY;
             int32_t kx = KEY_NONE;
             if (i < n) {
@@ -324,23 +338,63 @@ __device__ void wg_select(int n, int rounds, F get, V *out_v, int32_t *out_k, Se
             }
             v[j] = x; key[j] = kx;
         }
-        wave_rounds<V, SEL_R>(v, key, rounds, sc->pv[wave], sc->pk[wave], lane);
-        __syncthreads();
-        if (wave == 0) {
-            constexpr int R2 = (NW * (K_MAX + 1) + 63) / 64;
-            V v2[R2];
-            int32_t k2[R2];
+        wave_rounds<V, R>(v, key, rounds, out_v, out_k, tid);
+    }
+    __syncthreads();
+}
+
+template <typename V, int R, typename F>
+__device__ __forceinline__ void wg_select_regs(int n, int rounds, F get, V *out_v, int32_t *out_k, SelScratch<V> *sc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = FIN_THREADS / 64;
+    V v[R];
+    int32_t key[R];
 #pragma unroll
-            for (int j = 0; j < R2; ++j) {
-                const int cnd = lane + j * 64;
-                const bool ok = cnd < NW * rounds;
-                const int p = ok ? cnd / rounds : 0, rr = ok ? cnd % rounds : 0;
-                v2[j] = ok ? sc->pv[p][rr] : (V)-INFINITY;
-                k2[j] = ok ? sc->pk[p][rr] : KEY_NONE;
-            }
-            wave_rounds<V, R2>(v2, k2, rounds, out_v, out_k, lane);
+    for (int j = 0; j < R; ++j) {
+        const int i = tid + j * FIN_THREADS;
+        V x = (V)-INFINITY;
+        int32_t kx = KEY_NONE;
+        if (i < n) {
+            V tv; int32_t tk;
+            if (get(i, tv, tk) && tv == tv) { x = tv; kx = tk; }
         }
-        __syncthreads();
+        v[j] = x; key[j] = kx;
+    }
+    wave_rounds<V, R>(v, key, rounds, sc->pv[wave], sc->pk[wave], lane);
+    __syncthreads();
+    if (wave == 0) {
+        constexpr int R2 = (NW * (K_MAX + 1) + 63) / 64;
+        V v2[R2];
+        int32_t k2[R2];
+#pragma unroll
+        for (int j = 0; j < R2; ++j) {
+            const int cnd = lane + j * 64;
+            const bool ok = cnd < NW * rounds;
+            const int p = ok ? cnd / rounds : 0, rr = ok ? cnd % rounds : 0;
+            v2[j] = ok ? sc->pv[p][rr] : (V)-INFINITY;
+            k2[j] = ok ? sc->pk[p][rr] : KEY_NONE;
+        }
+        wave_rounds<V, R2>(v2, k2, rounds, out_v, out_k, lane);
+    }
+    __syncthreads();
+}
+
+// Workgroup selection over n candidates.  get(i, v, key) -> bool valid; keys unique, < KEY_NONE.
+// n <= 4096: candidates live in registers, each wave extracts its own `rounds` winners, wave 0
+// merges the 4 lists (2 barriers in all).  Larger n: one global sweep per round (slow, rare).
+// Results land in out_v/out_k (shared memory) and are visible to every thread on return.
+template <typename V, typename F>
+__device__ void wg_select(int n, int rounds, F get, V *out_v, int32_t *out_k, SelScratch<V> *sc) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = FIN_THREADS / 64;
+    if (n <= 64 * SEL_R) {
+        // n <= 1024 (the usual case): one wave holds every candidate, no merge stage, one barrier
+        if (n <= 64 * 8) wave_select_single<V, 8>(n, rounds, get, out_v, out_k);
+        else wave_select_single<V, SEL_R>(n, rounds, get, out_v, out_k);
+        return;
+    }
+    if (n <= SEL_FAST_MAX) {
+        wg_select_regs<V, SEL_R>(n, rounds, get, out_v, out_k, sc);
         return;
     }
     V pv = (V)INFINITY;
@@ -381,34 +435,28 @@ __device__ void wg_select(int n, int rounds, F get, V *out_v, int32_t *out_k, Se
 }
 
 // ---------------------------------------------------------------------------------------------
-// finalize: one workgroup per query of the current chunk
+// finalize, in three launches so the exact re-score runs wide instead of inside one workgroup:
+//   select_kernel   grid Q        picks the KS best tasks, then the KS best tiles inside them
+//   rescore_kernel  grid (KS, Q)  exact fp64 dots of the 32 rows of one candidate tile
+//   rank_kernel     grid Q        (-dot64, +row) top-k of the KS*32 candidates + the certificate
 // ---------------------------------------------------------------------------------------------
-template <typename T, int PER>
-__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
-    const T *__restrict__ q, const T *__restrict__ gal, int64_t N, int k, int ks, int ntiles, int tpt,
-    int ntasks, int qpad, const float *__restrict__ bmax, const float *__restrict__ tmax, float scale,
-    float eps_coef, int32_t *__restrict__ idx, float *__restrict__ score, double *__restrict__ dot64,
-    int32_t *__restrict__ status, int32_t *__restrict__ need_exact)
+struct FinMeta { float bound; float qnorm; };   // per query: best excluded approx max, ||q||_2
+
+__global__ __launch_bounds__(FIN_THREADS) void select_kernel(
+    int ks, int ntiles, int tpt, int ntasks, int qpad, const float *__restrict__ bmax,
+    const float *__restrict__ tmax, int32_t *__restrict__ sel_tiles /*[Q][KS_MAX]*/, FinMeta *__restrict__ meta)
 {
-    constexpr int E = PER * 64;
-    __shared__ SelScratch<double> scd;
     __shared__ SelScratch<float> scf;
     __shared__ float sel_v[KS_MAX + 1];
     __shared__ int32_t sel_task[KS_MAX + 1];
     __shared__ int32_t sel_tile[KS_MAX + 1];
-    __shared__ double cand_s[KS_MAX * TILE_ROWS];
-    __shared__ double out_v[K_MAX];
-    __shared__ int32_t out_k[K_MAX];
-
-    const int qi = blockIdx.x;  // query slot inside the chunk (q, idx... are already chunk-offset)
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int qi = blockIdx.x, tid = threadIdx.x;
 
     // level 1: best ks tasks (+1 to learn the best excluded one)
     wg_select<float>(ntasks, ks + 1, [&](int i, float &v, int32_t &key) {
         v = tmax[(size_t)i * qpad + qi]; key = i; return true; }, sel_v, sel_task, &scf);
     const float bound1 = sel_v[ks];  // -inf when no task was left out
     __syncthreads();
-
     // level 2: best ks tiles among the selected tasks' tiles, ordered by (-max, +tile)
     wg_select<float>(ks * tpt, ks + 1, [&](int i, float &v, int32_t &key) {
         const int32_t task = sel_task[i / tpt];
@@ -416,48 +464,62 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
         const int32_t tile = task * tpt + (i % tpt);
         if (tile >= ntiles) return false;
         v = bmax[(size_t)tile * qpad + qi]; key = tile; return true; }, sel_v, sel_tile, &scf);
-    const float bound2 = sel_v[ks];
-    __syncthreads();
+    if (tid < ks) sel_tiles[(size_t)qi * KS_MAX + tid] = sel_tile[tid];
+    if (tid == 0) meta[qi].bound = fmaxf(bound1, sel_v[ks]);
+}
 
-    // level 3: exact fp64 re-score of the candidate rows, 16 lanes per row, 4 rows in flight per lane
-    const int m = lane & 15;
+template <typename T, int PER>
+__global__ __launch_bounds__(FIN_THREADS) void rescore_kernel(
+    const T *__restrict__ q, const T *__restrict__ gal, int64_t N, const int32_t *__restrict__ sel_tiles,
+    double *__restrict__ cand /*[Q][KS_MAX*32]*/, FinMeta *__restrict__ meta)
+{
+    constexpr int E = PER * 64;
+    const int slot = blockIdx.x, qi = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, grp = tid >> 4;   // 16 row groups
+    const int32_t tile = sel_tiles[(size_t)qi * KS_MAX + slot];
     QuadQuery<T, PER> qq;
     qq.load(q + (size_t)qi * E, m);
-    double qn2 = 0.0;
+    QuadRow<T, PER> gr[2];
+    bool live[2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) qn2 += chunk_partial<PER>(qq.v[i], qq.v[i]);
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) qn2 += __shfl_xor(qn2, off, 64);
-
-    const int ncand = ks * TILE_ROWS;            // multiple of 32
-    const int grp = tid >> 4;                    // 16 row groups per pass
-    constexpr int UN = 2;
-    for (int j0 = 0; j0 < ncand; j0 += 16 * UN) {
-        QuadRow<T, PER> gr[UN];
-        bool live[UN];
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const int j = j0 + u * 16 + grp;
-            const int32_t tile = sel_tile[j / TILE_ROWS];
-            const int64_t row = (int64_t)tile * TILE_ROWS + (j % TILE_ROWS);
-            live[u] = tile != KEY_NONE && row < N;
-            gr[u].load(gal + (size_t)(live[u] ? row : 0) * E, m);
-        }
-#pragma unroll
-        for (int u = 0; u < UN; ++u) {
-            const double s = quad_dot<T, PER>(qq, gr[u]);
-            if (m == 0) cand_s[j0 + u * 16 + grp] = live[u] ? s : -INFINITY;
-        }
+    for (int u = 0; u < 2; ++u) {
+        const int64_t row = (int64_t)tile * TILE_ROWS + u * 16 + grp;
+        live[u] = tile != KEY_NONE && row < N;
+        gr[u].load(gal + (size_t)(live[u] ? row : 0) * E, m);
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const double s = quad_dot<T, PER>(qq, gr[u]);
+        if (m == 0) cand[((size_t)qi * KS_MAX + slot) * TILE_ROWS + u * 16 + grp] = live[u] ? s : -INFINITY;
+    }
+    if (slot == 0 && grp == 0) {   // ||q||: sizes the certificate's margin
+        double qn2 = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qn2 += chunk_partial<PER>(qq.v[i], qq.v[i]);
+#pragma unroll
+        for (int off = 8; off >= 1; off >>= 1) qn2 += __shfl_xor(qn2, off, 64);
+        if (m == 0) meta[qi].qnorm = (float)sqrt(qn2);
+    }
+}
 
-    wg_select<double>(ncand, k, [&](int i, double &v, int32_t &key) {
-        const int32_t tile = sel_tile[i / TILE_ROWS];
+__global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
+    int64_t N, int k, int ks, const int32_t *__restrict__ sel_tiles, const double *__restrict__ cand,
+    const FinMeta *__restrict__ meta, float scale, float eps_coef, int32_t *__restrict__ idx,
+    float *__restrict__ score, double *__restrict__ dot64, int32_t *__restrict__ status,
+    int32_t *__restrict__ need_exact)
+{
+    __shared__ SelScratch<double> scd;
+    __shared__ double out_v[K_MAX];
+    __shared__ int32_t out_k[K_MAX];
+    const int qi = blockIdx.x, tid = threadIdx.x;
+    const int32_t *st = sel_tiles + (size_t)qi * KS_MAX;
+    const double *cs = cand + (size_t)qi * KS_MAX * TILE_ROWS;
+    wg_select<double>(ks * TILE_ROWS, k, [&](int i, double &v, int32_t &key) {
+        const int32_t tile = st[i / TILE_ROWS];
         if (tile == KEY_NONE) return false;
         const int64_t row = (int64_t)tile * TILE_ROWS + (i % TILE_ROWS);
         if (row >= N) return false;
-        key = (int32_t)row; v = cand_s[i]; return true; }, out_v, out_k, &scd);
-
+        key = (int32_t)row; v = cs[i]; return true; }, out_v, out_k, &scd);
     if (tid < k) {
         const size_t o = (size_t)qi * k + tid;
         const bool has = out_k[tid] != KEY_NONE;
@@ -468,8 +530,8 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(
     if (tid == 0) {
         // Certificate: every excluded tile's max (an fp32 MFMA dot) is <= bound; a row of an excluded
         // tile can only displace the k-th pick if its exact dot reaches kth, i.e. if bound + err >= kth.
-        const double bound = (double)fmaxf(bound1, bound2);
-        const double eps = (double)eps_coef * sqrt(qn2);
+        const double bound = (double)meta[qi].bound;
+        const double eps = (double)eps_coef * (double)meta[qi].qnorm;
         const int kk = (int)(N < k ? N : k);
         const bool ok = (bound == -INFINITY) || (out_k[kk - 1] != KEY_NONE && out_v[kk - 1] > bound + eps);
         need_exact[qi] = ok ? 0 : 1;
@@ -678,7 +740,7 @@ struct SearchPlan {
     int ntiles, tpt, ntasks, nslab, ks;
     int64_t rows_per_slab;
     bool fast;  // MFMA scan usable
-    size_t off_bmax, off_tmax, off_flags, off_partial, total;
+    size_t off_bmax, off_tmax, off_flags, off_partial, off_seltiles, off_cand, off_meta, total;
 };
 
 static bool scan_supports_E(int E) { return E == 128 || E == 256 || E == 512 || E == 768; }
@@ -706,6 +768,9 @@ static SearchPlan make_plan(int64_t N, int E, int Q, int k, mmr_dtype dt)
     p.off_tmax = off; off += align_up((size_t)p.ntasks * qc * sizeof(float), 256);
     p.off_flags = off; off += align_up((size_t)(Q > 0 ? Q : 1) * sizeof(int32_t), 256);
     p.off_partial = off; off += align_up((size_t)(Q > 0 ? Q : 1) * p.nslab * K_MAX * sizeof(ExhEntry), 256);
+    p.off_seltiles = off; off += align_up((size_t)qc * KS_MAX * sizeof(int32_t), 256);
+    p.off_cand = off; off += align_up((size_t)qc * KS_MAX * TILE_ROWS * sizeof(double), 256);
+    p.off_meta = off; off += align_up((size_t)qc * sizeof(FinMeta), 256);
     p.total = off;
     return p;
 }
@@ -733,11 +798,17 @@ static int launch_scan(const bf16_t *q, const bf16_t *gal, int Qc, int64_t N, co
 template <typename T, int PER>
 static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, const SearchPlan &p, int qpad,
                            const float *bmax, const float *tmax, float scale, float eps_coef, int32_t *idx,
-                           float *score, double *dot64, int32_t *status, int32_t *flags, hipStream_t st)
+                           float *score, double *dot64, int32_t *status, int32_t *flags, int32_t *sel_tiles,
+                           double *cand, FinMeta *meta, hipStream_t st)
 {
     ProfScope prof(MMR_PROF_FINALIZE, st);
-    hipLaunchKernelGGL((finalize_kernel<T, PER>), dim3(Qc), dim3(FIN_THREADS), 0, st, q, gal, N, k, p.ks, p.ntiles,
-                       p.tpt, p.ntasks, qpad, bmax, tmax, scale, eps_coef, idx, score, dot64, status, flags);
+    hipLaunchKernelGGL(select_kernel, dim3(Qc), dim3(FIN_THREADS), 0, st, p.ks, p.ntiles, p.tpt, p.ntasks, qpad, bmax,
+                       tmax, sel_tiles, meta);
+    MMR_CHECK_LAUNCH();
+    hipLaunchKernelGGL((rescore_kernel<T, PER>), dim3(p.ks, Qc), dim3(FIN_THREADS), 0, st, q, gal, N, sel_tiles, cand, meta);
+    MMR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rank_kernel, dim3(Qc), dim3(FIN_THREADS), 0, st, N, k, p.ks, sel_tiles, cand, meta, scale, eps_coef,
+                       idx, score, dot64, status, flags);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
@@ -830,7 +901,9 @@ extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dty
                 rc = launch_finalize<bf16_t, PER>(qc, (const bf16_t *)gallery, Qc, N, k, p, qpad, bmax, tmax, scale,
                                                   eps_coef, idx + (size_t)q0 * k, score + (size_t)q0 * k,
                                                   dot64 ? dot64 + (size_t)q0 * k : nullptr,
-                                                  status ? status + q0 : nullptr, flags + q0, st);
+                                                  status ? status + q0 : nullptr, flags + q0,
+                                                  (int32_t *)(ws + p.off_seltiles), (double *)(ws + p.off_cand),
+                                                  (FinMeta *)(ws + p.off_meta), st);
             });
             if (rc != MMR_OK) return rc;
         }
