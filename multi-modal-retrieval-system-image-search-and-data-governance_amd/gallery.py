@@ -1,0 +1,147 @@
+"""Gallery build: drive the image tower over a dataset in batches and keep / persist the [N,E] matrix.
+
+Counterpart of the reference's per-image loops:
+    build_cache          reference code/search_image.py:142-165  (batch-1 loop, two PCIe hops per image,
+                                                                  pickle of {relpath: float32[512]})
+    pre_load_features    reference code/utils.py:135-157         (DataLoader batches -> {split}_f.pt / _l.pt)
+    build_cache_model    reference code/utils.py:99-132          (keys_{shots}shots.pt / values_...)
+Here the loop body is one batched ``encode_image`` per <= batch_size images; features stay on the
+GPU (bf16 by default, the search kernel's gallery dtype) and are only copied to the host when a
+cache file in the reference's format is asked for.
+"""
+import os
+import pickle
+from typing import Callable, Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+def _images_of(batch):
+    """DataLoader-style batches are (images, labels[, paths]); bare tensors are accepted too."""
+    if isinstance(batch, torch.Tensor):
+        return batch, None
+    if isinstance(batch, (tuple, list)) and len(batch) >= 1 and isinstance(batch[0], torch.Tensor):
+        return batch[0], (batch[1] if len(batch) > 1 else None)
+    raise TypeError(f"cannot find an image tensor in a batch of type {type(batch)}")
+
+
+@torch.no_grad()
+def encode_gallery(model, batches: Iterable, normalize: bool = True, out_dtype: torch.dtype = torch.bfloat16,
+                   return_labels: bool = False):
+    """Encode every batch of ``batches`` -> device tensor [N,E] (rows in arrival order).
+
+    ``model`` is a ``mmr_amd.CLIP``; each batch is a float tensor [b,3,S,S] (or a DataLoader tuple whose
+    first item is one).  ``normalize`` fuses the reference's ``f /= f.norm(dim=-1, keepdim=True)``
+    into the encoder's last kernel.  Host batches are uploaded with non-blocking copies so the upload
+    of batch i+1 overlaps the encode of batch i when the loader yields pinned memory.
+    """
+    prev_dtype = model.dtype
+    model.to(out_dtype)
+    feats: List[torch.Tensor] = []
+    labels: List[torch.Tensor] = []
+    try:
+        for batch in batches:
+            images, lab = _images_of(batch)
+            if images.numel() == 0:
+                continue
+            feats.append(model.encode_image(images.to(model.device, non_blocking=True), normalize=normalize))
+            if lab is not None:
+                labels.append(torch.as_tensor(lab))
+    finally:
+        model.to(prev_dtype)
+    out = torch.cat(feats) if feats else torch.empty(0, model.cfg.embed_dim, dtype=out_dtype, device=model.device)
+    if return_labels:
+        return out, (torch.cat(labels) if labels else None)
+    return out
+
+
+def batched(items: Sequence, load: Callable, batch_size: int = 256):
+    """Yield stacked [b,3,S,S] tensors from ``load(item)`` results (one preprocessed image each)."""
+    buf = []
+    for it in items:
+        buf.append(load(it))
+        if len(buf) == batch_size:
+            yield torch.stack(buf)
+            buf = []
+    if buf:
+        yield torch.stack(buf)
+
+
+# ------------------------------------------------------------------ reference cache formats
+def save_feature_cache(path: str, keys: Sequence[str], features: torch.Tensor) -> None:
+    """Write ``./caches/search/features.pkl``'s format: a pickled dict {relpath: np.float32[E]}
+    (reference code/search_image.py:158-160)."""
+    if len(keys) != features.shape[0]:
+        raise ValueError(f"{len(keys)} keys for {features.shape[0]} feature rows")
+    arr = features.detach().to("cpu", torch.float32).numpy()
+    d = {k: np.ascontiguousarray(arr[i]) for i, k in enumerate(keys)}
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "wb") as f:
+        pickle.dump(d, f)
+
+
+def load_feature_cache(path: str) -> Tuple[List[str], torch.Tensor]:
+    """Read a features.pkl written by ``save_feature_cache`` or by the reference's ``build_cache``
+    (reference code/search_image.py:162-164).  Pickle executes code from the file: only load caches
+    you (or the reference run you trust) wrote."""
+    with open(path, "rb") as f:
+        d = pickle.load(f)
+    keys = list(d.keys())
+    feats = torch.from_numpy(np.stack([np.asarray(d[k], dtype=np.float32).reshape(-1) for k in keys])) if keys \
+        else torch.empty(0, 0)
+    return keys, feats
+
+
+def build_cache(model, keys: Sequence[str], load: Callable, cache_path: Optional[str] = None,
+                batch_size: int = 256, out_dtype: torch.dtype = torch.bfloat16):
+    """``build_cache`` of the reference (code/search_image.py:142-165) with a batched loop body.
+
+    ``load(key)`` returns the preprocessed [3,S,S] tensor of one image.  Returns (keys, features [N,E]
+    on the GPU, L2-normalised).  If ``cache_path`` exists it is loaded instead of re-encoding, and if
+    given it is (re)written in the reference's pickle format.
+    """
+    if cache_path and os.path.exists(cache_path):
+        k, f = load_feature_cache(cache_path)
+        return k, f.to(model.device, out_dtype)
+    feats = encode_gallery(model, batched(keys, load, batch_size), normalize=True, out_dtype=out_dtype)
+    if cache_path:
+        save_feature_cache(cache_path, keys, feats)
+    return list(keys), feats
+
+
+def save_split_features(cache_dir: str, split: str, features: torch.Tensor, labels: torch.Tensor) -> None:
+    """``{split}_f.pt`` / ``{split}_l.pt`` of ``pre_load_features`` (reference code/utils.py:150-151)."""
+    os.makedirs(cache_dir, exist_ok=True)
+    torch.save(features.detach().cpu(), os.path.join(cache_dir, f"{split}_f.pt"))
+    torch.save(labels.detach().cpu(), os.path.join(cache_dir, f"{split}_l.pt"))
+
+
+def load_split_features(cache_dir: str, split: str):
+    """Counterpart of reference code/utils.py:154-155 (tensors only: ``weights_only=True``)."""
+    f = torch.load(os.path.join(cache_dir, f"{split}_f.pt"), weights_only=True)
+    l = torch.load(os.path.join(cache_dir, f"{split}_l.pt"), weights_only=True)
+    return f, l
+
+
+@torch.no_grad()
+def build_cache_model(model, loader_factory: Callable[[], Iterable], augment_epoch: int, num_classes: int,
+                      cache_dir: Optional[str] = None, shots: int = 0):
+    """Tip-Adapter cache keys / values (reference code/utils.py:99-132): keys = mean over
+    ``augment_epoch`` passes of the encoded few-shot set, L2-normalised, transposed to [E, N];
+    values = one-hot labels [N, C].  ``loader_factory()`` returns a fresh iterable of (images, target)."""
+    from .search import l2_normalize
+
+    acc, values = None, None
+    for ep in range(augment_epoch):
+        f, lab = encode_gallery(model, loader_factory(), normalize=False, out_dtype=torch.float32, return_labels=True)
+        acc = f if acc is None else acc + f
+        if ep == 0:
+            values = lab
+    keys = l2_normalize(acc / float(augment_epoch)).t().contiguous()
+    vals = torch.nn.functional.one_hot(values.long().to(model.device), num_classes).to(torch.float32)
+    if cache_dir:
+        os.makedirs(cache_dir, exist_ok=True)
+        torch.save(keys.cpu(), os.path.join(cache_dir, f"keys_{shots}shots.pt"))
+        torch.save(vals.cpu(), os.path.join(cache_dir, f"values_{shots}shots.pt"))
+    return keys, vals

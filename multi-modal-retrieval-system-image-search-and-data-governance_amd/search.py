@@ -53,6 +53,11 @@ def similarity(features: torch.Tensor, ref_feature: torch.Tensor, scale: float =
     use ``cosine_topk`` for large ones.
     """
     r2, squeezed = _as_2d(ref_feature)
+    if features.is_cuda and r2.dtype != features.dtype:
+        # mixed precision (e.g. bf16 cache rows scored against an fp32 mean vector): this is the
+        # small-gallery API, so widen both operands to fp32 rather than round the reference vector
+        features = features.to(torch.float32)
+        r2 = r2.to(torch.float32)
     q, g = _prep_pair(r2, features)
     Q, E = q.shape
     N = g.shape[0]

@@ -249,3 +249,39 @@ def test_batch_256_vitb32_matches_oracle_on_sample(device):
         ref = clip_ref.l2_normalize(clip_ref.encode_image(w, model.cfg.vision, px[[0, 255]].bfloat16().float()))
     cos = _cos(f[[0, 255]].float().cpu(), ref)
     assert cos.min().item() >= 1 - 1e-3
+
+
+def test_encode_gallery_and_cache(device, tmp_path):
+    """Row C1: batched gallery build == per-batch encode_image; cache file round-trips; build_cache reuses it."""
+    from mmr_amd import gallery
+    model, _ = mmr_amd.load("tiny-test", device=device)
+    S = model.input_resolution
+    imgs = synth.synth_images(21, S, seed=9)
+    labels = torch.arange(21) % 3
+    batches = [(imgs[0:8], labels[0:8]), (imgs[8:16], labels[8:16]), (imgs[16:21], labels[16:21])]   # ragged tail
+    g, lab = gallery.encode_gallery(model, batches, normalize=True, out_dtype=torch.bfloat16, return_labels=True)
+    assert g.shape == (21, model.cfg.embed_dim) and g.dtype == torch.bfloat16 and g.is_cuda and torch.equal(lab, labels)
+    assert model.dtype == torch.float32                        # caller's dtype setting is restored
+    model.bfloat16()
+    ref = torch.cat([model.encode_image(b[0].to(device), normalize=True) for b in batches])
+    model.float()
+    assert torch.equal(g, ref)
+    assert gallery.encode_gallery(model, []).shape == (0, model.cfg.embed_dim)
+    keys = [f"c{i % 3}/{i}.jpg" for i in range(21)]
+    calls = []
+
+    def load(k):
+        calls.append(k)
+        return imgs[keys.index(k)]
+
+    path = str(tmp_path / "features.pkl")
+    k1, f1 = gallery.build_cache(model, keys, load, path, batch_size=8)
+    assert k1 == keys and torch.equal(f1, g) and len(calls) == 21
+    k2, f2 = gallery.build_cache(model, keys, load, path, batch_size=8)         # second call: served from the cache
+    assert len(calls) == 21 and torch.equal(f2, g)
+    # the reference's get_similarity over the cached rows
+    sim = mmr_amd.similarity(f2, f2[:4].float().mean(0), 100.0)
+    assert torch.allclose(sim, 100.0 * f2.float() @ f2[:4].float().mean(0), atol=2e-3)
+    kk, vv = gallery.build_cache_model(model, lambda: batches, augment_epoch=2, num_classes=3)
+    assert kk.shape == (model.cfg.embed_dim, 21) and vv.shape == (21, 3)
+    assert torch.allclose(kk.norm(dim=0), torch.ones(21, device=device), atol=1e-4)

@@ -172,3 +172,31 @@ def test_sharded_search_world2_gloo():
     results = sorted(q.get(timeout=5) for _ in range(2))
     assert results == [(0, True), (1, True)]
     assert all(p.exitcode == 0 for p in procs)
+
+
+# ------------------------------------------------------------------ gallery cache formats (host-side)
+def test_feature_cache_formats_round_trip(tmp_path):
+    from mmr_amd import gallery
+    import pickle
+
+    feats = synth.synth_unit_rows(7, 512, seed=3).bfloat16()
+    keys = [f"cls{i % 2}/img_{i}.jpg" for i in range(7)]
+    p = tmp_path / "caches" / "search" / "features.pkl"
+    gallery.save_feature_cache(str(p), keys, feats)
+    # exactly what the reference's build_cache reads back: dict {relpath: np.float32[512]}
+    d = pickle.load(open(p, "rb"))
+    assert list(d.keys()) == keys and d[keys[3]].dtype == np.float32 and d[keys[3]].shape == (512,)
+    k2, f2 = gallery.load_feature_cache(str(p))
+    assert k2 == keys and torch.equal(f2, feats.float())
+    # a cache written the reference's way (per-image .cpu().numpy() rows) loads the same
+    ref_style = {k: feats[i].float().numpy() for i, k in enumerate(keys)}
+    pickle.dump(ref_style, open(tmp_path / "ref.pkl", "wb"))
+    k3, f3 = gallery.load_feature_cache(str(tmp_path / "ref.pkl"))
+    assert k3 == keys and torch.equal(f3, feats.float())
+    with pytest.raises(ValueError):
+        gallery.save_feature_cache(str(p), keys[:3], feats)
+    labels = torch.arange(7)
+    gallery.save_split_features(str(tmp_path / "c"), "val", feats.float(), labels)
+    f4, l4 = gallery.load_split_features(str(tmp_path / "c"), "val")
+    assert torch.equal(f4, feats.float()) and torch.equal(l4, labels)
+    assert [b.shape[0] for b in gallery.batched(list(range(10)), lambda i: torch.zeros(3, 4, 4), 4)] == [4, 4, 2]
