@@ -70,6 +70,14 @@ int mmr_l2norm_rows(void *x, mmr_dtype dtype, int64_t rows, int E, void *stream)
 int mmr_topk_merge(const int64_t *idx_parts, const double *dot_parts, int parts, int Q, int k, float scale,
                    int64_t *idx, float *score, double *dot64, void *stream);
 
+/* Tip-Adapter logits, fused (replaces reference code/main_custom.py:111,124-127 and
+ * code/utils.py:182-186):  tip = 100*F@W + alpha * (exp(-(beta - beta*(F@Kc))) @ V * 10).
+ *   features[N,E]; clip_weights_t[C,E] = W^T; cache_keys_t[S,E] = Kc^T (all `dtype`);
+ *   cache_values[S,C] fp32; tip_logits[N,C] fp32; clip_logits[N,C] fp32 (nullable) = 100*F@W.  C <= 64. */
+int mmr_tip_adapter_logits(const void *features, const void *clip_weights_t, const void *cache_keys_t,
+                           const float *cache_values, mmr_dtype dtype, int64_t N, int E, int C, int S, float alpha,
+                           float beta, float *tip_logits, float *clip_logits, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Encoder towers  (replaces model.encode_image / encode_text of the `clip` package and
  * CLIPModel.get_image_features of transformers; arithmetic per SURVEY.md Appendix A).

@@ -25,6 +25,7 @@ _LAZY = {
     "load": "clip", "tokenize": "clip", "CLIP": "clip",
     "similarity": "search", "cosine_topk": "search", "l2_normalize": "search",
     "GalleryIndex": "search", "ShardedGalleryIndex": "search", "merge_topk": "search",
+    "tip_adapter_logits": "search", "encode_gallery": "gallery", "build_cache": "gallery",
 }
 
 

@@ -654,6 +654,51 @@ __global__ __launch_bounds__(256) void similarity_kernel(const T *__restrict__ q
     }
 }
 
+// Tip-Adapter logits, fused (reference code/main_custom.py:111,124-127, code/utils.py:182-186):
+//   clip_logits  = 100 * F @ W                      F[N,E], W^T given as wt[C,E]
+//   affinity     = F @ Kc                           Kc^T given as kt[S,E]
+//   cache_logits = exp(-(beta - beta*affinity)) @ V * 10        V[S,C]
+//   tip_logits   = clip_logits + alpha * cache_logits
+// One wave per feature row: the row stays in registers, every key/class row is a coalesced read,
+// the [N,S] affinity matrix is never written.  fp32 accumulate.
+template <typename T, int PER>
+__global__ __launch_bounds__(256) void tip_logits_kernel(const T *__restrict__ f, const T *__restrict__ wt,
+                                                          const T *__restrict__ kt, const float *__restrict__ v,
+                                                          int64_t N, int C, int S, float alpha, float beta,
+                                                          float *__restrict__ tip, float *__restrict__ clip)
+{
+    constexpr int E = PER * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+    if (n >= N) return;
+    float fv[PER];
+    load_chunk<T, PER>(f + (size_t)n * E, lane, fv);
+    float my_clip = 0.f, my_cache = 0.f;      // lane c < C owns class c
+    for (int c = 0; c < C; ++c) {
+        float xv[PER];
+        load_chunk<T, PER>(wt + (size_t)c * E, lane, xv);
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) p += fv[j] * xv[j];
+        p = wave_sum(p);
+        if (lane == c) my_clip = 100.f * p;
+    }
+    for (int s = 0; s < S; ++s) {
+        float xv[PER];
+        load_chunk<T, PER>(kt + (size_t)s * E, lane, xv);
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) p += fv[j] * xv[j];
+        p = wave_sum(p);
+        const float e = __expf(-(beta - beta * p));
+        if (lane < C) my_cache += e * v[(size_t)s * C + lane];
+    }
+    if (lane < C) {
+        tip[(size_t)n * C + lane] = my_clip + alpha * (my_cache * 10.f);
+        if (clip) clip[(size_t)n * C + lane] = my_clip;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void l2norm_kernel(T *__restrict__ x, int64_t rows, int E)
 {
@@ -984,6 +1029,34 @@ extern "C" int mmr_topk_merge(const int64_t *idx_parts, const double *dot_parts,
     MMR_CHECK_ARG(parts * k <= 1024, "mmr_topk_merge: parts*k=%d exceeds 1024", parts * k);
     hipLaunchKernelGGL(merge_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, idx_parts, dot_parts, parts, Q, k,
                        scale, idx, score, dot64);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+extern "C" int mmr_tip_adapter_logits(const void *features, const void *clip_weights_t, const void *cache_keys_t,
+                                      const float *cache_values, mmr_dtype dtype, int64_t N, int E, int C, int S,
+                                      float alpha, float beta, float *tip_logits, float *clip_logits, void *stream)
+{
+    MMR_CHECK_ARG(dtype == MMR_F32 || dtype == MMR_BF16, "mmr_tip_adapter_logits: dtype %d", (int)dtype);
+    MMR_CHECK_ARG(N >= 0 && C >= 1 && C <= 64 && S >= 0, "mmr_tip_adapter_logits: bad shape N=%lld C=%d S=%d (C <= 64)", (long long)N, C, S);
+    if (N == 0) return MMR_OK;
+    MMR_CHECK_ARG(features && clip_weights_t && tip_logits && (S == 0 || (cache_keys_t && cache_values)), "mmr_tip_adapter_logits: null pointer");
+    MMR_CHECK_ARG((((uintptr_t)features | (uintptr_t)clip_weights_t | (uintptr_t)cache_keys_t) & 15) == 0, "mmr_tip_adapter_logits: operands must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)((N + 3) / 4));
+    if (dtype == MMR_BF16) {
+        MMR_DISPATCH_PER(E, bf16_t, {
+            hipLaunchKernelGGL((tip_logits_kernel<bf16_t, PER>), grid, dim3(256), 0, st, (const bf16_t *)features,
+                               (const bf16_t *)clip_weights_t, (const bf16_t *)cache_keys_t, cache_values, N, C, S, alpha,
+                               beta, tip_logits, clip_logits);
+        });
+    } else {
+        MMR_DISPATCH_PER(E, float, {
+            hipLaunchKernelGGL((tip_logits_kernel<float, PER>), grid, dim3(256), 0, st, (const float *)features,
+                               (const float *)clip_weights_t, (const float *)cache_keys_t, cache_values, N, C, S, alpha,
+                               beta, tip_logits, clip_logits);
+        });
+    }
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }

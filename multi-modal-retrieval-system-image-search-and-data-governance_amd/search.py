@@ -68,6 +68,41 @@ def similarity(features: torch.Tensor, ref_feature: torch.Tensor, scale: float =
     return out[0] if squeezed else out.t()
 
 
+def tip_adapter_logits(features: torch.Tensor, clip_weights: torch.Tensor, cache_keys: torch.Tensor,
+                       cache_values: torch.Tensor, alpha: float, beta: float, return_clip_logits: bool = False):
+    """Fused Tip-Adapter scoring (reference code/main_custom.py:111,124-127):
+
+        clip_logits  = 100. * features @ clip_weights                      # clip_weights [E,C]
+        affinity     = features @ cache_keys                               # cache_keys   [E,S]
+        cache_logits = ((-1) * (beta - beta * affinity)).exp() @ cache_values * 10     # values [S,C]
+        tip_logits   = clip_logits + cache_logits * alpha
+
+    Returns fp32 ``tip_logits [N,C]`` (and ``clip_logits``).  The [N,S] affinity matrix is never written.
+    """
+    if not features.is_cuda:
+        raise RuntimeError("features must live on the GPU (there is no CPU path)")
+    dt = features.dtype if features.dtype in (torch.float32, torch.bfloat16) else torch.float32
+    if clip_weights.dtype != dt or cache_keys.dtype != dt:
+        dt = torch.float32
+    dev = features.device
+    f = features.to(dt).contiguous()
+    wt = clip_weights.to(dev, dt).t().contiguous()                 # [C,E]
+    kt = cache_keys.to(dev, dt).t().contiguous()                   # [S,E]
+    v = cache_values.to(dev, torch.float32).contiguous()           # [S,C]
+    N, E = f.shape
+    C, S = wt.shape[0], kt.shape[0]
+    if wt.shape[1] != E or kt.shape[1] != E or v.shape != (S, C):
+        raise ValueError(f"shape mismatch: features {tuple(f.shape)}, clip_weights {tuple(clip_weights.shape)}, "
+                         f"cache_keys {tuple(cache_keys.shape)}, cache_values {tuple(cache_values.shape)}")
+    tip = torch.empty(N, C, dtype=torch.float32, device=dev)
+    clip = torch.empty(N, C, dtype=torch.float32, device=dev) if return_clip_logits else None
+    L = _lib.lib()
+    _lib.check(L.mmr_tip_adapter_logits(f.data_ptr(), wt.data_ptr(), kt.data_ptr(), v.data_ptr(), _lib.dtype_code(dt),
+                                        N, E, C, S, float(alpha), float(beta), tip.data_ptr(), _lib.ptr(clip),
+                                        _lib.stream_ptr(dev)))
+    return (tip, clip) if return_clip_logits else tip
+
+
 def _local_topk(q, g, k, scale, norm_bound, want_dot64, want_status, workspace=None):
     Q, E = q.shape
     N = g.shape[0]

@@ -193,3 +193,28 @@ def test_full_size_1m_gallery_exact(S, oracle, device):
     assert np.array_equal(idx_c[sample].numpy(), oi)
     assert np.array_equal(d_c[sample].numpy(), od)
     print("status (queries on exhaustive path):", int(status.sum()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_tip_adapter_logits_matches_reference_expression(S, device, dtype):
+    """Row 8f-3: the fused op vs the reference's own expression (code/main_custom.py:111,124-127) in fp32."""
+    N, E, C, shots = 333, 512, 6, 16
+    f = synth.synth_unit_rows(N, E, seed=41).to(dtype)
+    W = synth.synth_unit_rows(C, E, seed=42).t().contiguous().to(dtype)               # clip_weights [E,C]
+    Kc = synth.synth_unit_rows(C * shots, E, seed=43).t().contiguous().to(dtype)      # cache_keys  [E,S]
+    V = torch.nn.functional.one_hot(torch.arange(C * shots) % C, C).float()           # cache_values [S,C]
+    alpha, beta = 1.17, 5.5
+    ff, Wf, Kf = f.float(), W.float(), Kc.float()
+    clip_logits = 100.0 * ff @ Wf
+    affinity = ff @ Kf
+    cache_logits = ((-1) * (beta - beta * affinity)).exp() @ V * 10
+    ref = clip_logits + cache_logits * alpha
+    tip, clip = S.tip_adapter_logits(f.to(device), W.to(device), Kc.to(device), V.to(device), alpha, beta,
+                                     return_clip_logits=True)
+    assert tip.shape == (N, C) and tip.dtype == torch.float32
+    assert (clip.cpu() - clip_logits).abs().max().item() <= 2e-3          # |logit| <= 100: 2e-5 relative
+    assert (tip.cpu() - ref).abs().max().item() <= 2e-3
+    # the ranking the reference derives from it (cls_acc, code/utils.py:17) is identical
+    assert torch.equal(tip.cpu().topk(1, 1, True, True)[1], ref.topk(1, 1, True, True)[1])
+    with pytest.raises(ValueError):
+        S.tip_adapter_logits(f.to(device), W[:100].to(device), Kc.to(device), V.to(device), alpha, beta)
