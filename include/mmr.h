@@ -137,6 +137,21 @@ int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_dtype, int B
                       size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Preprocess  (replaces the PIL/torchvision `preprocess` applied per image at reference
+ * code/search_image.py:127,155: Resize(BICUBIC) -> CenterCrop -> ToTensor -> Normalize).
+ * ---------------------------------------------------------------------------------------- */
+
+/* img: uint8 RGB [H,W,3].  The coefficient tables are Pillow's (precompute_coeffs +
+ * normalize_coeffs_8bpc) for the S columns / rows of the centre-crop window, built on the host
+ * (preprocess.py): bounds int32[S][2] = (first input index, taps), coeffs int32[S][k] in 22-bit
+ * fixed point.  row0/rows = the input rows the vertical pass reads; tmp: uint8 [rows,S,3] scratch.
+ * out: [3,S,S] fp32 or bf16 = ((u8/255) - mean) / std; out_u8 (nullable): the uint8 [S,S,3] crop. */
+int mmr_preprocess_image(const uint8_t *img, int H, int W, int S, int row0, int rows, const int32_t *hbounds,
+                         const int32_t *hcoeffs, int hk, const int32_t *vbounds, const int32_t *vcoeffs, int vk,
+                         float mean0, float mean1, float mean2, float std0, float std1, float std2, uint8_t *tmp,
+                         void *out, mmr_dtype out_dtype, uint8_t *out_u8, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Launch profiler (measurement aid for bench.py): HIP event pairs around every kernel launch of a
  * class, recorded on the launch stream.  Off by default.
  * ---------------------------------------------------------------------------------------- */

@@ -60,6 +60,9 @@ def lib():
     L.mmr_topk_merge.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
     L.mmr_tip_adapter_logits.restype = i32
     L.mmr_tip_adapter_logits.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, i32, f32, f32, vp, vp, vp]
+    L.mmr_preprocess_image.restype = i32
+    L.mmr_preprocess_image.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, f32, f32, f32, f32, f32,
+                                       f32, vp, vp, i32, vp, vp]
     L.mmr_prof_enable.restype = i32
     L.mmr_prof_enable.argtypes = [i32, i32]
     L.mmr_prof_read.restype = i32

@@ -264,36 +264,28 @@ class CLIP:
     __call__ = forward
 
 
-def _preprocess_factory(n_px: int):
-    """Host-side stand-in for the ``preprocess`` transform ``clip.load`` returns: bicubic resize of
-    the shorter side to n_px, centre crop, /255, normalise with the CLIP mean/std
-    (reference code/custom.py:28; use sites code/search_image.py:127,155).  Accepts a PIL image, an
-    HWC uint8 array, or a CHW tensor.  Data loading is outside the hot path."""
-    mean = torch.tensor(CLIP_MEAN).view(3, 1, 1)
-    std = torch.tensor(CLIP_STD).view(3, 1, 1)
+def _preprocess_factory(n_px: int, device: torch.device):
+    """The ``preprocess`` callable ``clip.load`` returns: Resize(n_px, BICUBIC) -> CenterCrop(n_px) ->
+    ToTensor -> Normalize(CLIP mean/std) (reference use sites code/search_image.py:127,155; constants
+    code/custom.py:28).  The decoded uint8 pixels are uploaded once and everything else runs in
+    csrc/preprocess.hip, bit-exact to Pillow's resize.  Accepts a PIL image, an HWC
+    uint8 array or tensor; returns float32 [3,n_px,n_px] ON THE MODEL'S DEVICE (the reference's following
+    ``.unsqueeze(0).cuda()`` / ``torch.stack(...).cuda()`` are then no-ops)."""
+    from .preprocess import preprocess_image
 
     def preprocess(img) -> torch.Tensor:
         if isinstance(img, torch.Tensor):
             x = img
-            if x.dim() == 3 and x.shape[0] != 3 and x.shape[-1] == 3:
-                x = x.permute(2, 0, 1)
         else:
             import numpy as np
 
             if hasattr(img, "convert"):
                 img = img.convert("RGB")
-            x = torch.from_numpy(np.asarray(img).copy()).permute(2, 0, 1)
-        x = x.to(torch.float32)
-        if x.max() > 1.5:
-            x = x / 255.0
-        _, h, w = x.shape
-        s = n_px / min(h, w)
-        nh, nw = max(n_px, round(h * s)), max(n_px, round(w * s))
-        x = torch.nn.functional.interpolate(x[None], size=(nh, nw), mode="bicubic", align_corners=False,
-                                            antialias=True)[0].clamp(0, 1)
-        top, left = (nh - n_px) // 2, (nw - n_px) // 2
-        x = x[:, top:top + n_px, left:left + n_px]
-        return (x - mean) / std
+            x = torch.from_numpy(np.ascontiguousarray(np.asarray(img)))
+        if x.dtype != torch.uint8 or x.dim() != 3 or x.shape[2] != 3:
+            raise TypeError("preprocess expects a PIL image or a uint8 [H,W,3] array/tensor "
+                            f"(got {x.dtype} {tuple(x.shape)})")
+        return preprocess_image(x.to(device, non_blocking=True), n_px)
 
     return preprocess
 
@@ -307,7 +299,7 @@ def load(name: str = "ViT-B/32", device: Union[str, torch.device] = "cuda", jit:
     if weights is None:
         weights = make_clip_weights(cfg, seed=seed)
     model = CLIP(cfg, weights, device)
-    return model, _preprocess_factory(cfg.vision.image_size)
+    return model, _preprocess_factory(cfg.vision.image_size, model.device)
 
 
 def tokenize(texts: Union[str, List[str], torch.Tensor, List[List[int]]], context_length: int = _CONTEXT,

@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api_common.cpp", "search.hip", "gemm.hip", "vit_ops.hip", "tower.hip"]
+SOURCES = ["api_common.cpp", "search.hip", "gemm.hip", "vit_ops.hip", "tower.hip", "preprocess.hip"]
 LIB = os.path.join(HERE, "libmmr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",

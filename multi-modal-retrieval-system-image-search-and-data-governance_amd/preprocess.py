@@ -1,0 +1,148 @@
+"""On-device CLIP preprocessing: bicubic resize of the shorter side, centre crop, /255, normalise.
+
+The step immediately before ``encode_image``.  The reference gets it
+from ``clip.load``'s ``preprocess`` -- torchvision ``Resize(n_px, BICUBIC)`` -> ``CenterCrop(n_px)`` ->
+``ToTensor`` -> ``Normalize(mean, std)`` on a PIL image (use sites code/search_image.py:127,155;
+constants code/custom.py:28).  The resize inside that is Pillow's ``Image.resize(..., BICUBIC)``:
+8-bit fixed-point separable convolution, horizontal pass then vertical pass, each rounded back to
+uint8 (Pillow src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc,
+ImagingResampleHorizontal_8bpc / Vertical_8bpc).  That is integer/byte arithmetic, so the device
+path reproduces it BIT-EXACTLY: the coefficient tables are built here on the host with the same
+double-precision steps Pillow takes, and csrc/preprocess.hip applies them in int32.
+
+Only the crop window is computed (same pixels as resize-then-crop, less work).
+"""
+import math
+from functools import lru_cache
+from typing import Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+PRECISION_BITS = 32 - 8 - 2      # Pillow Resample.c
+
+
+def _bicubic(x: float) -> float:
+    a = -0.5                      # Pillow's bicubic_filter
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+@lru_cache(maxsize=256)
+def resample_tables(in_size: int, out_size: int, first: int, count: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for outputs [first, first+count) of a
+    full-box resize in_size -> out_size.  Returns (bounds int32[count,2] = (xmin, taps),
+    coeffs int32[count, ksize], ksize)."""
+    scale = float(np.float32(in_size) - np.float32(0.0)) / out_size      # (double)(in1 - in0) / outSize, box is float
+    filterscale = max(scale, 1.0)
+    support = 2.0 * filterscale                                          # bicubic support = 2
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((count, 2), np.int32)
+    coeffs = np.zeros((count, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for j in range(count):
+        xx = first + j
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in k:
+            ww += w
+        if ww != 0.0:
+            k = [w / ww for w in k]
+        for x, w in enumerate(k):
+            coeffs[j, x] = int(-0.5 + w * (1 << PRECISION_BITS)) if w < 0 else int(0.5 + w * (1 << PRECISION_BITS))
+        bounds[j] = (xmin, xmax)
+    return bounds, coeffs, ksize
+
+
+def resize_geometry(h: int, w: int, n_px: int):
+    """torchvision Resize(int) + CenterCrop(int) geometry: shorter side -> n_px, the other
+    int(n_px * long / short); crop offsets int(round((size - n_px) / 2.0)) (Python round)."""
+    if w <= h:
+        nw, nh = n_px, int(n_px * h / w)
+    else:
+        nh, nw = n_px, int(n_px * w / h)
+    top = int(round((nh - n_px) / 2.0))
+    left = int(round((nw - n_px) / 2.0))
+    return nh, nw, top, left
+
+
+_table_cache = {}
+
+
+def _device_tables(h, w, n_px, device):
+    key = (h, w, n_px, str(device))
+    hit = _table_cache.get(key)
+    if hit is not None:
+        return hit
+    nh, nw, top, left = resize_geometry(h, w, n_px)
+    hb, hc, hk = resample_tables(w, nw, left, n_px)       # horizontal: columns of the crop window
+    vb, vc, vk = resample_tables(h, nh, top, n_px)        # vertical: rows of the crop window
+    row0 = int(vb[:, 0].min())
+    row1 = int((vb[:, 0] + vb[:, 1]).max())               # input rows the vertical pass touches
+    t = dict(hb=torch.from_numpy(hb).to(device), hc=torch.from_numpy(hc).to(device), hk=hk,
+             vb=torch.from_numpy(vb).to(device), vc=torch.from_numpy(vc).to(device), vk=vk, row0=row0, row1=row1)
+    if len(_table_cache) > 512:
+        _table_cache.clear()
+    _table_cache[key] = t
+    return t
+
+
+@torch.no_grad()
+def preprocess_image(img_u8: torch.Tensor, n_px: int = 224, out: torch.Tensor = None,
+                     out_dtype: torch.dtype = torch.float32, mean: Sequence[float] = CLIP_MEAN,
+                     std: Sequence[float] = CLIP_STD, return_u8: bool = False):
+    """uint8 RGB image [H,W,3] on the GPU -> normalised [3,n_px,n_px] (fp32 or bf16).
+
+    Equals ``Normalize(ToTensor(CenterCrop(Resize(PIL image))))`` bit for bit in the uint8 stage and in
+    fp32 arithmetic after it.  ``return_u8`` also returns the resized+cropped uint8 [n_px,n_px,3].
+    """
+    if img_u8.dtype != torch.uint8 or img_u8.dim() != 3 or img_u8.shape[2] != 3:
+        raise ValueError(f"expected a uint8 [H,W,3] tensor, got {img_u8.dtype} {tuple(img_u8.shape)}")
+    if not img_u8.is_cuda:
+        raise RuntimeError("image must live on the GPU (there is no CPU path); upload the decoded bytes first")
+    img_u8 = img_u8.contiguous()
+    h, w = int(img_u8.shape[0]), int(img_u8.shape[1])
+    dev = img_u8.device
+    t = _device_tables(h, w, n_px, dev)
+    rows = t["row1"] - t["row0"]
+    tmp = torch.empty(rows, n_px, 3, dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.empty(3, n_px, n_px, dtype=out_dtype, device=dev)
+    u8 = torch.empty(n_px, n_px, 3, dtype=torch.uint8, device=dev) if return_u8 else None
+    L = _lib.lib()
+    _lib.check(L.mmr_preprocess_image(img_u8.data_ptr(), h, w, n_px, t["row0"], rows,
+                                      t["hb"].data_ptr(), t["hc"].data_ptr(), t["hk"],
+                                      t["vb"].data_ptr(), t["vc"].data_ptr(), t["vk"],
+                                      float(mean[0]), float(mean[1]), float(mean[2]),
+                                      float(std[0]), float(std[1]), float(std[2]),
+                                      tmp.data_ptr(), out.data_ptr(), _lib.dtype_code(out.dtype), _lib.ptr(u8),
+                                      _lib.stream_ptr(dev)))
+    return (out, u8) if return_u8 else out
+
+
+def preprocess_batch(images: Sequence[torch.Tensor], n_px: int = 224, out_dtype: torch.dtype = torch.float32):
+    """A list of uint8 [H_i,W_i,3] GPU tensors (any sizes) -> [B,3,n_px,n_px]."""
+    if not images:
+        raise ValueError("empty batch")
+    dev = images[0].device
+    out = torch.empty(len(images), 3, n_px, n_px, dtype=out_dtype, device=dev)
+    for i, im in enumerate(images):
+        preprocess_image(im, n_px, out=out[i], out_dtype=out_dtype)
+    return out

@@ -1,0 +1,87 @@
+"""Preprocess: host coefficient tables vs Pillow on the CPU; HIP kernel vs Pillow on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+SIZES = [(37, 53), (224, 224), (300, 200), (200, 300), (1000, 751), (97, 640), (224, 225), (64, 64), (231, 500)]
+
+
+def _img(h, w, seed):
+    rng = np.random.default_rng(seed)
+    base = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    if seed % 2:                      # smooth-ish content as well as noise
+        yy, xx = np.mgrid[0:h, 0:w]
+        base = ((np.sin(yy / 7.0)[..., None] * 90 + np.cos(xx / 11.0)[..., None] * 90 + 128
+                 + rng.integers(-20, 20, (h, w, 3)))).clip(0, 255).astype(np.uint8)
+    return base
+
+
+def _apply_tables(img, n_px):
+    """Pure-numpy application of the product's tables (int32 math), to check them without a GPU."""
+    from mmr_amd import preprocess as P
+    h, w = img.shape[:2]
+    nh, nw, top, left = P.resize_geometry(h, w, n_px)
+    hb, hc, _ = P.resample_tables(w, nw, left, n_px)
+    vb, vc, _ = P.resample_tables(h, nh, top, n_px)
+    half = 1 << (P.PRECISION_BITS - 1)
+    src = img.astype(np.int64)
+    tmp = np.zeros((h, n_px, 3), np.int64)
+    for x in range(n_px):
+        x0, n = hb[x]
+        acc = half + (src[:, x0:x0 + n, :] * hc[x, :n, None].astype(np.int64)).sum(axis=1)
+        tmp[:, x, :] = np.clip(acc >> P.PRECISION_BITS, 0, 255)
+    out = np.zeros((n_px, n_px, 3), np.uint8)
+    for y in range(n_px):
+        y0, n = vb[y]
+        acc = half + (tmp[y0:y0 + n] * vc[y, :n, None, None].astype(np.int64)).sum(axis=0)
+        out[y] = np.clip(acc >> P.PRECISION_BITS, 0, 255)
+    return out
+
+
+@pytest.mark.parametrize("hw", SIZES)
+@pytest.mark.parametrize("n_px", [224, 64])
+def test_tables_reproduce_pillow_bit_exact(hw, n_px):
+    from oracle import preprocess_ref
+    img = _img(hw[0], hw[1], seed=hw[0] + hw[1])
+    assert np.array_equal(_apply_tables(img, n_px), preprocess_ref.preprocess_u8(img, n_px))
+
+
+def test_geometry_matches_oracle():
+    from mmr_amd import preprocess as P
+    from oracle import preprocess_ref
+    for h, w in SIZES + [(225, 224), (449, 224), (224, 1000)]:
+        for n in (224, 336):
+            assert P.resize_geometry(h, w, n) == preprocess_ref.geometry(h, w, n)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hw", SIZES)
+def test_hip_preprocess_bit_exact_vs_pillow(device, hw):
+    from mmr_amd import preprocess as P
+    from oracle import preprocess_ref
+    img = _img(hw[0], hw[1], seed=hw[0] * 3 + hw[1])
+    for n_px in (224, 64):
+        out, u8 = P.preprocess_image(torch.from_numpy(img).to(device), n_px, return_u8=True)
+        assert np.array_equal(u8.cpu().numpy(), preprocess_ref.preprocess_u8(img, n_px))     # byte-exact resize+crop
+        ref = preprocess_ref.preprocess(img, n_px)
+        assert torch.equal(out.cpu(), ref)                                                   # and fp32-exact normalise
+    ob = P.preprocess_image(torch.from_numpy(img).to(device), 224, out_dtype=torch.bfloat16)
+    assert torch.equal(ob.cpu(), preprocess_ref.preprocess(img, 224).bfloat16())
+
+
+@pytest.mark.gpu
+def test_preprocess_feeds_encoder(device):
+    import mmr_amd
+    from mmr_amd import preprocess as P
+    from oracle import preprocess_ref
+    model, _ = mmr_amd.load("tiny-test", device=device)
+    imgs = [_img(80 + 13 * i, 120 - 7 * i, seed=i) for i in range(5)]
+    batch = P.preprocess_batch([torch.from_numpy(a).to(device) for a in imgs], model.input_resolution)
+    ref = torch.stack([preprocess_ref.preprocess(a, model.input_resolution) for a in imgs])
+    assert torch.equal(batch.cpu(), ref)
+    f = model.encode_image(batch)
+    assert f.shape == (5, model.cfg.embed_dim) and torch.isfinite(f).all()
+    with pytest.raises(ValueError):
+        P.preprocess_image(torch.zeros(4, 4, 3, device=device))
+    with pytest.raises(RuntimeError):
+        P.preprocess_image(torch.zeros(4, 4, 3, dtype=torch.uint8))
