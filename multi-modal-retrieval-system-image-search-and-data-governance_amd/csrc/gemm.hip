@@ -110,6 +110,17 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
         cur ^= 1;
     }
 
+#ifdef MMR_GEMM_NOEPI   // diagnostic build: time prologue + main loop only (outputs are wrong)
+    {
+        float keep = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (keep == 123.456f) ((float *)out)[0] = keep;
+        return;
+    }
+#endif
     // ---- epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + {0,1,2,3}]
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -124,10 +135,11 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
             const size_t o = (size_t)m * N + n;
             if constexpr (EPI == EPI_BIAS_GELU_BF16) {
                 // QuickGELU x * sigmoid(1.702 x)  (transformers/activations.py:117-123)
-                v0 = v0 / (1.f + __expf(-1.702f * v0));
-                v1 = v1 / (1.f + __expf(-1.702f * v1));
-                v2 = v2 / (1.f + __expf(-1.702f * v2));
-                v3 = v3 / (1.f + __expf(-1.702f * v3));
+                // same formulation as the 256x256 kernel, so features do not depend on which tile size ran
+                v0 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v0));
+                v1 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v1));
+                v2 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v2));
+                v3 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v3));
             }
             if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
                 uint2 pk;
