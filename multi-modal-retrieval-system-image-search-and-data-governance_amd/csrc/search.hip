@@ -24,6 +24,7 @@
 #include "mmr_common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace mmr {
 
@@ -801,6 +802,10 @@ static SearchPlan make_plan(int64_t N, int E, int Q, int k, mmr_dtype dt)
         const int m = (p.ntiles + 256 * MAX_TPT - 1) / (256 * MAX_TPT);
         p.tpt = (p.ntiles + 256 * m - 1) / (256 * m);
     }
+    // test hook: force the tiles-per-task count (1..64) to reach the large-task-count selection paths
+    // with a small gallery
+    static const int force_tpt = getenv("MMR_SEARCH_TPT") ? atoi(getenv("MMR_SEARCH_TPT")) : 0;
+    if (force_tpt >= 1 && force_tpt <= MAX_TPT) p.tpt = force_tpt;
     p.ntasks = (p.ntiles + p.tpt - 1) / p.tpt;
     p.ks = k + 6 > KS_MAX ? KS_MAX : k + 6;
     p.fast = dt == MMR_BF16 && scan_supports_E(E) && k + 6 <= KS_MAX && N > 0;

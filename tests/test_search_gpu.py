@@ -218,3 +218,28 @@ def test_tip_adapter_logits_matches_reference_expression(S, device, dtype):
     assert torch.equal(tip.cpu().topk(1, 1, True, True)[1], ref.topk(1, 1, True, True)[1])
     with pytest.raises(ValueError):
         S.tip_adapter_logits(f.to(device), W[:100].to(device), Kc.to(device), V.to(device), alpha, beta)
+
+
+def test_selection_paths_for_many_tasks(device):
+    """Task counts above 1024 (register selection over 4 waves) and above 4096 (global sweep per round) are
+    reached by very large shards; MMR_SEARCH_TPT=1 reaches them with a small gallery (separate process: the
+    hook is read once per process)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np, torch
+        sys.path.insert(0, %r)
+        from mmr_amd import search, synth
+        from oracle import search_ref
+        dev = torch.device("cuda:0")
+        for N in (50_000, 150_000):          # 1563 and 4688 one-tile tasks
+            gal = synth.synth_unit_rows(N, 256, seed=5).bfloat16()
+            q = synth.synth_unit_rows(5, 256, seed=6).bfloat16()
+            v, i, d, st = search.cosine_topk(q.to(dev), gal.to(dev), 10, return_dot64=True, return_status=True)
+            oi, _, od = search_ref.cosine_topk(q, gal, 10)
+            assert np.array_equal(i.cpu().numpy(), oi) and np.array_equal(d.cpu().numpy(), od), N
+            assert int(st.sum()) == 0
+        print("ok")
+    """ % (str(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))),))
+    env = dict(__import__("os").environ, MMR_SEARCH_TPT="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
