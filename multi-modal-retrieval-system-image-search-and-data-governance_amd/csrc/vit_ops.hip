@@ -312,6 +312,156 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// attention core for long sequences (T = 257, 577: ViT-L/14): flash-style streaming.
+//   grid (ceil(T/64), heads, B); a workgroup owns 64 queries (one 16-query block per wave) and streams
+//   the head's keys/values in blocks of 64 through a double-buffered 34 KiB LDS image, so several
+//   workgroups share a CU and the next block's global loads (issued to registers before the block's
+//   MFMAs, written to LDS after them) overlap the current block's compute.  Online softmax: running
+//   max per query, un-normalised bf16 P, one rescale of the 64x16 output tile per key block.
+// ---------------------------------------------------------------------------------------------
+constexpr int AKB = 64;                       // keys per block
+constexpr int AV_STR = AKB * 2 + 8;           // bytes per V^T row (+8 breaks the power-of-two stride)
+constexpr int ABUF = AKB * 128 + 64 * AV_STR; // one buffer: K [64][64] bf16 + V^T [64][64(+4)] bf16
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
+                                                               int T, int d, float scale)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hd = blockIdx.y, b = blockIdx.z;
+    const size_t ld = (size_t)3 * d;
+    const bf16_t *base = qkv + (size_t)b * T * ld + hd * 64;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int qi = (blockIdx.x * 4 + wave) * 16 + fr;      // this lane's query
+    const int nkb = (T + AKB - 1) / AKB;
+
+    bf16x8 qf[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        qf[s] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (qi < T) qf[s] = *reinterpret_cast<const bf16x8 *>(base + (size_t)qi * ld + s * 32 + fg * 8);
+    }
+
+    // each thread moves 2 K chunks and 2 V chunks (16 B each) per key block
+    uint4 kreg[2], vreg[2];
+    auto gload = [&](int kb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 256, row = id >> 3, c = id & 7, key = kb * AKB + row;
+            kreg[i] = make_uint4(0, 0, 0, 0);
+            vreg[i] = make_uint4(0, 0, 0, 0);
+            if (key < T) {
+                kreg[i] = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + d + c * 8);
+                vreg[i] = *reinterpret_cast<const uint4 *>(base + (size_t)key * ld + 2 * d + c * 8);
+            }
+        }
+    };
+    auto lwrite = [&](int buf) {
+        char *Ks = smem + buf * ABUF, *Vt = Ks + AKB * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + i * 256, row = id >> 3, c = id & 7;
+            *reinterpret_cast<uint4 *>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[i];
+            const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<bf16_t *>(Vt + (c * 8 + e) * AV_STR + row * 2) = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+        }
+    };
+
+    float m = -INFINITY, l = 0.f;             // running max (uniform over the 4 lanes of a query), partial sum
+    f32x4 oacc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int buf = kb & 1;
+        if (kb + 1 < nkb) gload(kb + 1);       // in flight during this block's MFMAs
+        const char *Ks = smem + buf * ABUF, *Vt = Ks + AKB * 128;
+
+        f32x4 sc[4];
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int row = jt * 16 + fr;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + row * 128 + (((s * 4 + fg) ^ (row & 7)) << 4));
+                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
+            }
+            sc[jt] = a;
+        }
+        float bm = -INFINITY;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kb * AKB + jt * 16 + fg * 4 + r;
+                float v = sc[jt][r] * scale;
+                if (key >= T || (CAUSAL && key > qi)) v = -INFINITY;
+                sc[jt][r] = v;
+                bm = fmaxf(bm, v);
+            }
+        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
+        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+        const float mn = fmaxf(m, bm);
+        const float msafe = mn == -INFINITY ? 0.f : mn;       // fully masked so far (causal padding rows)
+        const float alpha = __expf(m - msafe);
+        m = mn;
+        float ps = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = __expf(sc[jt][r] - msafe);
+                sc[jt][r] = p;
+                ps += p;
+            }
+        l = l * alpha + ps;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            union { bf16x8 v; uint32_t u[4]; } pf;
+            pf.u[0] = pack_bf16x2(sc[2 * s2][0], sc[2 * s2][1]);
+            pf.u[1] = pack_bf16x2(sc[2 * s2][2], sc[2 * s2][3]);
+            pf.u[2] = pack_bf16x2(sc[2 * s2 + 1][0], sc[2 * s2 + 1][1]);
+            pf.u[3] = pack_bf16x2(sc[2 * s2 + 1][2], sc[2 * s2 + 1][3]);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const char *vr = Vt + (dt * 16 + fr) * AV_STR + (32 * s2 + 4 * fg) * 2;
+                union { bf16x8 v; uint2 h[2]; } vf;
+                vf.h[0] = *reinterpret_cast<const uint2 *>(vr);
+                vf.h[1] = *reinterpret_cast<const uint2 *>(vr + 32);
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, oacc[dt], 0, 0, 0);
+            }
+        }
+        if (kb + 1 < nkb) lwrite(buf ^ 1);     // the other buffer was last read in iteration kb-1
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.f / l;
+    if (qi < T) {
+        bf16_t *dst = o + ((size_t)b * T + qi) * d + hd * 64 + fg * 4;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            uint2 pk;
+            pk.x = pack_bf16x2(oacc[dt][0] * inv, oacc[dt][1] * inv);
+            pk.y = pack_bf16x2(oacc[dt][2] * inv, oacc[dt][3] * inv);
+            *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers (internal; argument validation is done by tower.hip)
 // ---------------------------------------------------------------------------------------------
 #define MMR_VPL_SWITCH(d, ...)                                                     \
@@ -404,17 +554,24 @@ static int launch_attention_t(const bf16_t *qkv, bf16_t *o, int Bn, int T, int h
 int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, int causal, hipStream_t st)
 {
     const int nt = (T + 31) / 32 * 2;
+    if (nt > 6) {   // long sequences: streaming kernel
+        ProfScope prof(MMR_PROF_ATTENTION, st);
+        const dim3 grid((T + 63) / 64, heads, Bn);
+        if (causal) hipLaunchKernelGGL(attention_stream_kernel<true>, grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+        else hipLaunchKernelGGL(attention_stream_kernel<false>, grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+        MMR_CHECK_LAUNCH();
+        return MMR_OK;
+    }
     if (!causal) {
         switch (nt) {
             case 2: return launch_attention_t<2, false>(qkv, o, Bn, T, heads, d, st);
             case 4: return launch_attention_t<4, false>(qkv, o, Bn, T, heads, d, st);
             case 6: return launch_attention_t<6, false>(qkv, o, Bn, T, heads, d, st);
-            case 18: return launch_attention_t<18, false>(qkv, o, Bn, T, heads, d, st);
-            case 38: return launch_attention_t<38, false>(qkv, o, Bn, T, heads, d, st);
         }
     } else {
         switch (nt) {
             case 2: return launch_attention_t<2, true>(qkv, o, Bn, T, heads, d, st);
+            case 4: return launch_attention_t<4, true>(qkv, o, Bn, T, heads, d, st);
             case 6: return launch_attention_t<6, true>(qkv, o, Bn, T, heads, d, st);
         }
     }

@@ -87,7 +87,8 @@ def test_layernorm(L, device, d):
     assert err <= 1e-2 * ref.abs().max().item(), err
 
 
-@pytest.mark.parametrize("T,causal", [(17, 0), (50, 0), (77, 1), (77, 0), (257, 0), (577, 0), (17, 1)])
+@pytest.mark.parametrize("T,causal", [(17, 0), (50, 0), (77, 1), (77, 0), (257, 0), (577, 0), (17, 1), (1, 0), (64, 1),
+                                      (97, 0), (130, 1), (608, 0)])
 def test_attention_core(L, device, T, causal):
     B, heads = 3, 2
     d = heads * 64
