@@ -142,21 +142,36 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
             f32x16 acc;
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-            // A fragments run PF k-steps ahead of the MFMA that consumes them, so LDS latency hides
-            // behind the (dependent) MFMA chain instead of being paid every other step.
+            // A fragments run PF k-steps ahead of the MFMA that consumes them.  hipcc waits lgkmcnt(0) in
+            // front of every second MFMA when it schedules these reads itself (each wait then exposes the
+            // LDS latency and the MFMA pipe idles half the time), so the reads are issued as inline asm and
+            // retired with COUNTED waits: the fragment consumed at step s was issued PF steps earlier and
+            // PF-1 younger reads may stay in flight.  The wait statement names the fragment "+v" so no use
+            // of it can be scheduled above the wait (cdna_hip_programming.md section 5.7, form ii).
             constexpr int PF = 4;
-            auto afrag = [&](int s) {
+            bf16x8 a[PF];
+            auto issue = [&](int s, bf16x8 &dst) {
                 const int chunk = 2 * s + h;
                 const int pos = (chunk & ~15) | ((chunk ^ c) & 15);
-                return *reinterpret_cast<const bf16x8 *>(tb + pos * 16);
+                const uint32_t addr = (uint32_t)(uintptr_t)(tb + pos * 16);   // LDS byte address
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
             };
-            bf16x8 a[PF];
 #pragma unroll
-            for (int s = 0; s < PF; ++s) a[s] = afrag(s);
+            for (int s = 0; s < PF; ++s) issue(s, a[s]);
 #pragma unroll
             for (int s = 0; s < C::KSTEPS; ++s) {
+                const int younger = (C::KSTEPS - 1 - s) < (PF - 1) ? (C::KSTEPS - 1 - s) : (PF - 1);
+                if (younger == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[s % PF]));
+                else if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[s % PF]));
+                else if (younger == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[s % PF]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[s % PF]));
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % PF], bq[s], acc, 0, 0, 0);
-                if (s + PF < C::KSTEPS) a[s % PF] = afrag(s + PF);
+                if (s + PF < C::KSTEPS) {
+                    // the MFMA above must have READ a[s % PF] before the next load overwrites it: the
+                    // empty statement ties the accumulator to this point so the load cannot move above it
+                    asm volatile("" : "+v"(acc));
+                    issue(s + PF, a[s % PF]);
+                }
             }
             // acc[i] = dot(query c, tile row (i&3) + 8*(i>>2) + 4*h)
             float m = -INFINITY;
