@@ -230,7 +230,7 @@ def main():
             "search_mqueries_per_s": round(QUERIES / (srch_ms * 1e-3) / 1e6, 4),
             "search_gpairs_per_s": round(QUERIES * GALLERY_ROWS * world / (srch_ms * 1e-3) / 1e9, 2),
             "roofline": {
-                "kernel": "gemm_bf16_kernel (all epilogues)", "bound": "mfma",
+                "kernel": "gemm256_bf16_kernel / gemm_bf16_kernel (all epilogues)", "bound": "mfma",
                 "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
                 "traffic": (traffic or {}).get("gemm_bytes_per_launch"),

@@ -148,7 +148,10 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
             // retired with COUNTED waits: the fragment consumed at step s was issued PF steps earlier and
             // PF-1 younger reads may stay in flight.  The wait statement names the fragment "+v" so no use
             // of it can be scheduled above the wait (cdna_hip_programming.md section 5.7, form ii).
-            constexpr int PF = 4;
+#ifndef MMR_SCAN_PF
+#define MMR_SCAN_PF 4
+#endif
+            constexpr int PF = MMR_SCAN_PF;
             bf16x8 a[PF];
             auto issue = [&](int s, bf16x8 &dst) {
                 const int chunk = 2 * s + h;
@@ -161,7 +164,11 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
 #pragma unroll
             for (int s = 0; s < C::KSTEPS; ++s) {
                 const int younger = (C::KSTEPS - 1 - s) < (PF - 1) ? (C::KSTEPS - 1 - s) : (PF - 1);
-                if (younger == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[s % PF]));
+                if (younger == 7) asm volatile("s_waitcnt lgkmcnt(7)" : "+v"(a[s % PF]));
+                else if (younger == 6) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a[s % PF]));
+                else if (younger == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a[s % PF]));
+                else if (younger == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[s % PF]));
+                else if (younger == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[s % PF]));
                 else if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[s % PF]));
                 else if (younger == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[s % PF]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[s % PF]));

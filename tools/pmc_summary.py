@@ -29,8 +29,9 @@ fetch = load(sys.argv[1], "FETCH_SIZE")
 write = load(sys.argv[2], "WRITE_SIZE")
 rows = {}
 for name in sorted(set(fetch) | set(write)):
-    if not any(k in name for k in ("scan_kernel", "gemm_bf16_kernel", "finalize_kernel", "attention_kernel",
-                                   "layernorm_kernel", "im2col", "embed_")):
+    if not any(k in name for k in ("scan_kernel", "gemm_bf16_kernel", "gemm256_bf16_kernel", "select_kernel",
+                                   "rescore_kernel", "rank_kernel", "attention_kernel", "layernorm_kernel",
+                                   "im2col", "embed_")):
         continue
     f, fn = fetch.get(name, (0.0, 0))
     w, wn = write.get(name, (0.0, 0))
@@ -42,9 +43,11 @@ for name in sorted(set(fetch) | set(write)):
                   "raw_WRITE_SIZE_KiB_per_launch": round(w / max(wn, 1), 1)}
     print(f"{name[:48]:48s} n={fn:5d} read {rd/1e6:10.2f} MB  write {wr/1e6:9.2f} MB per launch")
 out = {"note": "per-launch HBM bytes from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes); "
-               "read side doubled per the gfx950 correction in MI355X_MICROARCH.md",
+               "read side doubled per the gfx950 correction in MI355X_MICROARCH.md, which is calibrated for "
+               "wide (16 B/lane) coalesced streams -- scan_kernel and the GEMM global_load_lds staging; for the "
+               "gather-style kernels (im2col, attention, select) it over-states reads by up to 2x",
        "kernels": rows}
-gemm = [v for k, v in rows.items() if k.startswith("gemm_bf16_kernel")]
+gemm = [v for k, v in rows.items() if k.startswith("gemm")]
 if gemm:
     tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in gemm)
     n = sum(v["launches"] for v in gemm)
