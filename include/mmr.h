@@ -84,12 +84,12 @@ int mmr_tip_adapter_logits(const void *features, const void *clip_weights_t, con
  * ---------------------------------------------------------------------------------------- */
 
 typedef struct {
-    int kind;        /* 0 = vision, 1 = text */
+    int kind;        /* 0 = CLIP vision, 1 = CLIP text, 2 = BERT-style text classifier (Taiyi) */
     int width;       /* d, multiple of 128 */
     int layers;
     int heads;       /* width / 64 */
     int mlp;         /* multiple of 128 */
-    int tokens;      /* vision: 1 + (image_size/patch)^2; text: context length */
+    int tokens;      /* vision: 1 + (image_size/patch)^2; text: context length; kind 2: max positions */
     int embed_dim;   /* E, multiple of 128 */
     int image_size;  /* vision only */
     int patch;       /* vision only */
@@ -105,6 +105,11 @@ typedef enum {
     MMR_P_LN1_W, MMR_P_LN1_B, MMR_P_QKV_W, MMR_P_QKV_B, MMR_P_OUT_W, MMR_P_OUT_B,
     MMR_P_LN2_W, MMR_P_LN2_B, MMR_P_FC1_W, MMR_P_FC1_B, MMR_P_FC2_W, MMR_P_FC2_B,
     MMR_P_LN_FINAL_W, MMR_P_LN_FINAL_B, MMR_P_PROJ, MMR_P_TOK_EMB,
+    /* BERT-style text encoder only (kind 2): */
+    MMR_P_TYPE_EMB, /* fp32 [2,d] token-type embeddings (row 0 is used) */
+    MMR_P_POOL_W,   /* bf16 [d,d] pooler dense */
+    MMR_P_POOL_B,   /* fp32 [d] */
+    MMR_P_PROJ_B,   /* fp32 [E] classifier bias (MMR_P_PROJ is the classifier weight [E,d]) */
     MMR_P_COUNT
 } mmr_param;
 
@@ -128,6 +133,15 @@ int mmr_vit_encode_image(mmr_tower *t, const void *pixels, mmr_dtype in_dtype, i
 /* ids[N,T] int32 (EOT = largest id per row) -> out[N,E]. */
 int mmr_text_encode(mmr_tower *t, const int32_t *ids, int N, void *out, mmr_dtype out_dtype, int normalize,
                     void *workspace, size_t workspace_bytes, void *stream);
+
+/* BERT-style text encoder (kind 2): replaces `text_encoder(text).logits` of
+ * BertForSequenceClassification (Taiyi-CLIP Chinese text tower; reference code/test_taiyi.py:12,24,
+ * CLIP-Chinese/lab_chinese.py:81-93).  Post-LN blocks, exact GELU, full attention over all T tokens (the
+ * reference passes no attention_mask), pooler = tanh(dense(first token)), classifier -> out[N,E].
+ * ids[N,T] int32 with 1 <= T <= cfg.tokens.  tap/tap_after as in mmr_tower_forward (after block i). */
+size_t mmr_bert_workspace_bytes(const mmr_tower *t, int N, int T);
+int mmr_bert_forward(mmr_tower *t, const int32_t *ids, int N, int T, void *out, mmr_dtype out_dtype, int normalize,
+                     int tap_after, float *tap, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Same forward with a tap on the fp32 residual stream for stage-level parity tests:
  * tap_after = -1 copies h after the embedding (+pre-LN for vision); i >= 0 after block i.
@@ -174,7 +188,8 @@ int mmr_prof_read(int cls, double *total_ms, long long *launches, long long *dro
  * ---------------------------------------------------------------------------------------- */
 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T): epi 0 = +bias -> bf16, 1 = +bias, QuickGELU -> bf16,
- * 2 = fp32 out += acc + bias, 3 = plain fp32.  M,N multiples of 128, K multiple of 64. */
+ * 2 = fp32 out += acc + bias, 3 = plain fp32, 4 = +bias -> fp32, 5 = +bias, exact GELU -> bf16,
+ * 6 = +bias, tanh -> bf16.  M,N multiples of 128, K multiple of 64. */
 int mmr_debug_gemm(int epi, const void *A, const void *W, int M, int N, int K, const float *bias, void *out,
                    void *stream);
 /* x_bf16[rows,d] = LayerNorm(h_f32[rows,d]) */

@@ -25,7 +25,7 @@ _LAZY = {
     "load": "clip", "tokenize": "clip", "CLIP": "clip",
     "similarity": "search", "cosine_topk": "search", "l2_normalize": "search",
     "GalleryIndex": "search", "ShardedGalleryIndex": "search", "merge_topk": "search",
-    "tip_adapter_logits": "search", "encode_gallery": "gallery", "build_cache": "gallery",
+    "tip_adapter_logits": "search", "load_text_encoder": "bert", "BertTextEncoder": "bert", "encode_gallery": "gallery", "build_cache": "gallery",
 }
 
 
@@ -36,7 +36,7 @@ def __getattr__(name):
 
         mod = importlib.import_module(f"{__name__}.{_LAZY[name]}")
         return getattr(mod, name)
-    if name in ("synth", "weights", "search", "clip", "config", "_lib", "gallery", "preprocess"):
+    if name in ("synth", "weights", "search", "clip", "config", "_lib", "gallery", "preprocess", "bert"):
         import importlib
 
         return importlib.import_module(f"{__name__}.{name}")

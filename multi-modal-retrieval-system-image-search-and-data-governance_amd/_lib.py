@@ -30,7 +30,7 @@ class TowerCfg(ctypes.Structure):
 # parameter ids, mirrored from include/mmr.h (mmr_param)
 (P_PATCH_W, P_CLS, P_POS, P_LN_PRE_W, P_LN_PRE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_OUT_W, P_OUT_B,
  P_LN2_W, P_LN2_B, P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B, P_LN_FINAL_W, P_LN_FINAL_B, P_PROJ, P_TOK_EMB,
- P_COUNT) = range(22)
+ P_TYPE_EMB, P_POOL_W, P_POOL_B, P_PROJ_B, P_COUNT) = range(26)
 
 _lib = None
 
@@ -86,6 +86,10 @@ def lib():
         L.mmr_text_encode.argtypes = [vp, vp, i32, vp, i32, i32, vp, sz, vp]
         L.mmr_tower_forward.restype = i32
         L.mmr_tower_forward.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, sz, vp]
+        L.mmr_bert_workspace_bytes.restype = sz
+        L.mmr_bert_workspace_bytes.argtypes = [vp, i32, i32]
+        L.mmr_bert_forward.restype = i32
+        L.mmr_bert_forward.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, sz, vp]
         L.mmr_debug_gemm.restype = i32
         L.mmr_debug_gemm.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp]
         L.mmr_debug_layernorm.restype = i32

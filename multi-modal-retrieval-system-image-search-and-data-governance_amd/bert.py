@@ -1,0 +1,137 @@
+"""BERT-style text classifier as a text tower (the Taiyi Chinese text encoder of the CN pipeline).
+
+Mirrors how the reference uses it (code/test_taiyi.py:12,24; CLIP-Chinese/lab_chinese.py:81-93):
+    text_encoder = BertForSequenceClassification.from_pretrained("IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chinese").eval()
+    text_features = text_encoder(text).logits          # text = tokenizer(..., padding=True)['input_ids']
+The call passes ids only, so all tokens (pads included) attend to each other with token type 0; that is what
+csrc/tower.hip::mmr_bert_forward computes.  Weights / vocabulary are not reachable offline: pass ``weights=``
+(names in weights.make_bert_weights) or get the seeded synthetic ones the golden fixtures use.
+"""
+import ctypes
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from .config import BertTextConfig, get_bert_config
+from .weights import make_bert_weights
+
+
+class BertTextEncoder:
+    max_batch = 512
+
+    def __init__(self, cfg: BertTextConfig, weights: Dict[str, torch.Tensor], device="cuda"):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("this encoder runs on MI355X only (device must be 'cuda'); there is no CPU path")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        self.cfg, self.device = cfg, device
+        self.L = _lib.lib()
+        self.c = _lib.TowerCfg(kind=2, width=cfg.width, layers=cfg.layers, heads=cfg.heads, mlp=cfg.mlp,
+                               tokens=cfg.max_positions, embed_dim=cfg.embed_dim, image_size=0, patch=0,
+                               vocab=cfg.vocab, ln_eps=cfg.ln_eps)
+        total = self.L.mmr_tower_weights_bytes(ctypes.byref(self.c))
+        if total == 0:
+            raise _lib.MMRError(-22, f"unsupported BERT geometry {cfg}")
+        blob = torch.zeros(total, dtype=torch.uint8)
+
+        def put(param, layer, tensor, as_bf16):
+            off, nbytes = ctypes.c_size_t(), ctypes.c_size_t()
+            _lib.check(self.L.mmr_tower_param_span(ctypes.byref(self.c), param, layer, ctypes.byref(off),
+                                                   ctypes.byref(nbytes)))
+            t = tensor.detach().to("cpu").contiguous()
+            raw = (t.to(torch.bfloat16) if as_bf16 else t.to(torch.float32)).view(torch.uint8).reshape(-1)
+            if raw.numel() != nbytes.value:
+                raise ValueError(f"tensor for param {param} has {raw.numel()} bytes, layout wants {nbytes.value}")
+            blob[off.value:off.value + nbytes.value] = raw
+
+        w = weights
+        put(_lib.P_TOK_EMB, 0, w["b.tok"], True)
+        put(_lib.P_POS, 0, w["b.pos"], False)
+        put(_lib.P_TYPE_EMB, 0, w["b.type"], False)
+        put(_lib.P_LN_PRE_W, 0, w["b.ln_emb.w"], False)
+        put(_lib.P_LN_PRE_B, 0, w["b.ln_emb.b"], False)
+        put(_lib.P_POOL_W, 0, w["b.pool.w"], True)
+        put(_lib.P_POOL_B, 0, w["b.pool.b"], False)
+        put(_lib.P_PROJ, 0, w["b.cls.w"], True)
+        put(_lib.P_PROJ_B, 0, w["b.cls.b"], False)
+        for i in range(cfg.layers):
+            for name, pid, bf in (("qkv.w", _lib.P_QKV_W, True), ("qkv.b", _lib.P_QKV_B, False),
+                                  ("out.w", _lib.P_OUT_W, True), ("out.b", _lib.P_OUT_B, False),
+                                  ("ln1.w", _lib.P_LN1_W, False), ("ln1.b", _lib.P_LN1_B, False),
+                                  ("fc1.w", _lib.P_FC1_W, True), ("fc1.b", _lib.P_FC1_B, False),
+                                  ("fc2.w", _lib.P_FC2_W, True), ("fc2.b", _lib.P_FC2_B, False),
+                                  ("ln2.w", _lib.P_LN2_W, False), ("ln2.b", _lib.P_LN2_B, False)):
+                put(pid, i, w[f"b.l{i}.{name}"], bf)
+        self.blob = blob.to(device)
+        handle = ctypes.c_void_p()
+        _lib.check(self.L.mmr_tower_create(ctypes.byref(self.c), self.blob.data_ptr(), self.blob.numel(),
+                                           ctypes.byref(handle)))
+        self.handle = handle
+        self._ws = None
+        self._dtype = torch.float32
+
+    def __del__(self):
+        h, self.handle = getattr(self, "handle", None), None
+        if h:
+            try:
+                self.L.mmr_tower_destroy(h)
+            except Exception:
+                pass
+
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def cuda(self, device=None):
+        return self
+
+    @property
+    def dtype(self):
+        return self._dtype
+
+    @torch.no_grad()
+    def logits(self, input_ids: torch.Tensor, normalize: bool = False, tap_after: int = -1,
+               tap: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if input_ids is None:
+            raise ValueError("You have to specify input_ids")
+        ids = torch.as_tensor(input_ids)
+        if ids.dim() == 1:
+            ids = ids.unsqueeze(0)
+        if ids.dim() != 2 or ids.dtype.is_floating_point:
+            raise ValueError(f"expected integer token ids [N,T], got {ids.dtype} {tuple(ids.shape)}")
+        N, T = ids.shape
+        if not 1 <= T <= self.cfg.max_positions:
+            raise ValueError(f"sequence length {T} outside [1,{self.cfg.max_positions}]")
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.cfg.vocab):
+            raise IndexError(f"token id outside [0,{self.cfg.vocab})")
+        ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty(N, self.cfg.embed_dim, dtype=self._dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            for s in range(0, N, self.max_batch):
+                n = min(self.max_batch, N - s)
+                need = self.L.mmr_bert_workspace_bytes(self.handle, n, T)
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+                _lib.check(self.L.mmr_bert_forward(self.handle, ids[s:s + n].data_ptr(), n, T, out[s:s + n].data_ptr(),
+                                                   _lib.dtype_code(self._dtype), int(bool(normalize)), int(tap_after),
+                                                   _lib.ptr(tap), self._ws.data_ptr(), self._ws.numel(),
+                                                   _lib.stream_ptr(self.device)))
+        return out
+
+    def __call__(self, input_ids=None, **_):
+        """``text_encoder(text).logits`` surface."""
+        return SimpleNamespace(logits=self.logits(input_ids))
+
+
+def load_text_encoder(name: str = "IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chinese", device="cuda",
+                      weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0) -> BertTextEncoder:
+    """Counterpart of ``BertForSequenceClassification.from_pretrained(name)`` for the Taiyi text tower."""
+    cfg = get_bert_config(name)
+    if weights is None:
+        weights = make_bert_weights(cfg, seed=seed)
+    return BertTextEncoder(cfg, weights, device)

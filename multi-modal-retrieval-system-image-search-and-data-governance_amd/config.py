@@ -64,6 +64,43 @@ MODEL_CONFIGS = {
     "tiny-test": _clip("tiny-test", 64, 16, 128, 2, 512, 128, 2, 512, 128, ctx=77, vocab=1024),
 }
 
+@dataclass(frozen=True)
+class BertTextConfig:
+    """BERT-style sequence classifier used as a text tower (its logits ARE the text embedding):
+    ``BertForSequenceClassification.from_pretrained("IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chinese")``
+    (reference code/test_taiyi.py:12,24; CLIP-Chinese/lab_chinese.py:81-93)."""
+    name: str
+    width: int
+    layers: int
+    heads: int
+    mlp: int
+    max_positions: int
+    vocab: int
+    embed_dim: int       # num_labels = dimension of the logits
+    ln_eps: float = 1e-12
+    kind: str = "bert"
+
+    @property
+    def tokens(self) -> int:
+        return self.max_positions
+
+
+BERT_CONFIGS = {
+    # Taiyi-CLIP-Roberta-large-326M-Chinese: BERT-large geometry, 21128-token Chinese vocabulary, 768-d logits
+    "Taiyi-CLIP-Roberta-large-326M-Chinese": BertTextConfig("Taiyi-CLIP-Roberta-large-326M-Chinese", 1024, 24, 16,
+                                                            4096, 512, 21128, 768),
+    "tiny-bert-test": BertTextConfig("tiny-bert-test", 128, 2, 2, 512, 64, 1000, 128),
+}
+BERT_ALIASES = {"IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chinese": "Taiyi-CLIP-Roberta-large-326M-Chinese"}
+
+
+def get_bert_config(name: str) -> BertTextConfig:
+    name = BERT_ALIASES.get(name, name)
+    if name not in BERT_CONFIGS:
+        raise RuntimeError(f"Text encoder {name} not found; available = {list(BERT_CONFIGS)}")
+    return BERT_CONFIGS[name]
+
+
 # HF hub ids the reference passes to from_pretrained, mapped to the same geometry.
 MODEL_ALIASES = {
     "openai/clip-vit-base-patch32": "ViT-B/32",

@@ -23,7 +23,27 @@ constexpr int TILE_A_BYTES = BM * BK * 2;  // 16 KiB
 constexpr int TILE_B_BYTES = BN * BK * 2;
 constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_B_BYTES;
 
-enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_STORE_F32 = 3 };
+enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_STORE_F32 = 3,
+       EPI_BIAS_F32 = 4, EPI_BIAS_GELU_ERF_BF16 = 5, EPI_BIAS_TANH_BF16 = 6, EPI_COUNT = 7 };
+
+constexpr bool epi_bf16(int e) { return e == EPI_BIAS_BF16 || e == EPI_BIAS_GELU_BF16 || e == EPI_BIAS_GELU_ERF_BF16 || e == EPI_BIAS_TANH_BF16; }
+constexpr bool epi_bias(int e) { return e != EPI_STORE_F32; }
+
+// activation fused into the bf16 epilogues
+template <int EPI>
+__device__ __forceinline__ float epi_act(float v) {
+    if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+        // QuickGELU x * sigmoid(1.702 x) (transformers/activations.py:117-123); hardware exp/rcp (1 ulp)
+        // is far inside bf16 rounding.  Same formulation in both tile sizes.
+        return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
+    } else if constexpr (EPI == EPI_BIAS_GELU_ERF_BF16) {
+        return 0.5f * v * (1.f + erff(v * 0.70710678118654752f));   // exact GELU (BERT "gelu")
+    } else if constexpr (EPI == EPI_BIAS_TANH_BF16) {
+        return tanhf(v);                                             // BERT pooler
+    } else {
+        return v;
+    }
+}
 
 // byte offset of 16-B chunk `c` (0..7) of tile row `row` inside a [rows][64] bf16 tile image
 __device__ __forceinline__ int tile_off(int row, int c) {
@@ -126,22 +146,14 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
     for (int ni = 0; ni < 4; ++ni) {
         const int n = n0 + wn * 64 + ni * 16 + fg * 4;
         float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (EPI != EPI_STORE_F32) b4 = *reinterpret_cast<const float4 *>(bias + n);
+        if constexpr (epi_bias(EPI)) b4 = *reinterpret_cast<const float4 *>(bias + n);
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + wm * 64 + mi * 16 + fr;
-            float v0 = acc[ni][mi][0] + b4.x, v1 = acc[ni][mi][1] + b4.y;
-            float v2 = acc[ni][mi][2] + b4.z, v3 = acc[ni][mi][3] + b4.w;
+            const float v0 = epi_act<EPI>(acc[ni][mi][0] + b4.x), v1 = epi_act<EPI>(acc[ni][mi][1] + b4.y);
+            const float v2 = epi_act<EPI>(acc[ni][mi][2] + b4.z), v3 = epi_act<EPI>(acc[ni][mi][3] + b4.w);
             const size_t o = (size_t)m * N + n;
-            if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-                // QuickGELU x * sigmoid(1.702 x)  (transformers/activations.py:117-123)
-                // same formulation as the 256x256 kernel, so features do not depend on which tile size ran
-                v0 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v0));
-                v1 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v1));
-                v2 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v2));
-                v3 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v3));
-            }
-            if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+            if constexpr (epi_bf16(EPI)) {
                 uint2 pk;
                 pk.x = pack_bf16x2(v0, v1);
                 pk.y = pack_bf16x2(v2, v3);
@@ -339,7 +351,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     char *my = smem + wave * 16384;
     const size_t row_base = (size_t)(m0 + wr * 128);
     const int col_base = n0 + wc * 64;
-    if constexpr (EPI == EPI_BIAS_BF16 || EPI == EPI_BIAS_GELU_BF16) {
+    if constexpr (epi_bf16(EPI)) {
         // image: [128 rows][8 chunks of 8 bf16], chunk index XOR (row & 7)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
@@ -347,15 +359,8 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
             const int c = ni * 2 + (fg >> 1);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
-                float v0 = acc[ni][mi][0] + b4.x, v1 = acc[ni][mi][1] + b4.y;
-                float v2 = acc[ni][mi][2] + b4.z, v3 = acc[ni][mi][3] + b4.w;
-                if constexpr (EPI == EPI_BIAS_GELU_BF16) {
-                    // QuickGELU x * sigmoid(1.702 x); hardware exp/rcp (1 ulp) is far inside bf16 rounding
-                    v0 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v0));
-                    v1 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v1));
-                    v2 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v2));
-                    v3 *= __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v3));
-                }
+                const float v0 = epi_act<EPI>(acc[ni][mi][0] + b4.x), v1 = epi_act<EPI>(acc[ni][mi][1] + b4.y);
+                const float v2 = epi_act<EPI>(acc[ni][mi][2] + b4.z), v3 = epi_act<EPI>(acc[ni][mi][3] + b4.w);
                 const int row = mi * 16 + fr;
                 uint2 pk;
                 pk.x = pack_bf16x2(v0, v1);
@@ -378,7 +383,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (EPI == EPI_BIAS_RESID_F32) b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
+                if constexpr (epi_bias(EPI)) b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
                 const int c = ni * 4 + fg;
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
@@ -418,6 +423,21 @@ static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K,
     return MMR_OK;
 }
 
+template <int EPI>
+static int launch_gemm128(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st)
+{
+    const int lds = 2 * STAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((M / BM) * (N / BN)), dim3(GEMM_THREADS), lds, st, A, W, M, N, K, bias, out);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
 // host launcher (internal): shapes are validated by the caller in tower.hip
 int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
                 hipStream_t st)
@@ -436,35 +456,21 @@ int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, 
             case EPI_BIAS_BF16: return launch_gemm256<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
             case EPI_BIAS_GELU_BF16: return launch_gemm256<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);
             case EPI_BIAS_RESID_F32: return launch_gemm256<EPI_BIAS_RESID_F32>(A, W, M, N, K, bias, out, st);
-            default: return launch_gemm256<EPI_STORE_F32>(A, W, M, N, K, bias, out, st);
+            case EPI_STORE_F32: return launch_gemm256<EPI_STORE_F32>(A, W, M, N, K, bias, out, st);
+            case EPI_BIAS_F32: return launch_gemm256<EPI_BIAS_F32>(A, W, M, N, K, bias, out, st);
+            case EPI_BIAS_GELU_ERF_BF16: return launch_gemm256<EPI_BIAS_GELU_ERF_BF16>(A, W, M, N, K, bias, out, st);
+            default: return launch_gemm256<EPI_BIAS_TANH_BF16>(A, W, M, N, K, bias, out, st);
         }
     }
-    const dim3 grid((M / BM) * (N / BN)), block(GEMM_THREADS);
-    const int lds = 2 * STAGE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI_BIAS_BF16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI_BIAS_GELU_BF16>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI_BIAS_RESID_F32>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI_STORE_F32>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
-    }
     switch (epi) {
-        case EPI_BIAS_BF16:
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_BF16>, grid, block, lds, st, A, W, M, N, K, bias, out); break;
-        case EPI_BIAS_GELU_BF16:
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_GELU_BF16>, grid, block, lds, st, A, W, M, N, K, bias, out); break;
-        case EPI_BIAS_RESID_F32:
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_BIAS_RESID_F32>, grid, block, lds, st, A, W, M, N, K, bias, out); break;
-        default:
-            hipLaunchKernelGGL(gemm_bf16_kernel<EPI_STORE_F32>, grid, block, lds, st, A, W, M, N, K, bias, out); break;
+        case EPI_BIAS_BF16: return launch_gemm128<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
+        case EPI_BIAS_GELU_BF16: return launch_gemm128<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);
+        case EPI_BIAS_RESID_F32: return launch_gemm128<EPI_BIAS_RESID_F32>(A, W, M, N, K, bias, out, st);
+        case EPI_STORE_F32: return launch_gemm128<EPI_STORE_F32>(A, W, M, N, K, bias, out, st);
+        case EPI_BIAS_F32: return launch_gemm128<EPI_BIAS_F32>(A, W, M, N, K, bias, out, st);
+        case EPI_BIAS_GELU_ERF_BF16: return launch_gemm128<EPI_BIAS_GELU_ERF_BF16>(A, W, M, N, K, bias, out, st);
+        default: return launch_gemm128<EPI_BIAS_TANH_BF16>(A, W, M, N, K, bias, out, st);
     }
-    MMR_CHECK_LAUNCH();
-    return MMR_OK;
 }
 
 }  // namespace mmr

@@ -11,7 +11,8 @@
 
 namespace mmr {
 // gemm.hip
-enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_STORE_F32 = 3 };
+enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_STORE_F32 = 3,
+       EPI_BIAS_F32 = 4, EPI_BIAS_GELU_ERF_BF16 = 5, EPI_BIAS_TANH_BF16 = 6 };
 int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st);
 // vit_ops.hip
 int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P, int G, int K, int Kpad, hipStream_t st);
@@ -20,6 +21,9 @@ int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, f
 int launch_layernorm(const float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps, hipStream_t st);
 int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const float *b, bf16_t *xc, int Nb, int T, int d, float eps, hipStream_t st);
 int launch_finish(const float *feat, void *out, mmr_dtype odt, int Nb, int E, int normalize, hipStream_t st);
+int launch_embed_bert(const int32_t *ids, const bf16_t *tok, const float *pos, const float *type0, const float *lw, const float *lb, float *h, bf16_t *x, int Nb, int T, int d, int vocab, float eps, hipStream_t st);
+int launch_layernorm_inplace(float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps, hipStream_t st);
+int launch_gather_first_rows(const bf16_t *x, bf16_t *xc, int Nb, int T, int d, hipStream_t st);
 int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, int causal, hipStream_t st);
 
 static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
@@ -30,7 +34,7 @@ static int patch_kpad(const mmr_tower_cfg &c) { return round_up(patch_k(c), 64);
 static const char *validate_cfg(const mmr_tower_cfg *c)
 {
     if (!c) return "null config";
-    if (c->kind != 0 && c->kind != 1) return "kind must be 0 (vision) or 1 (text)";
+    if (c->kind < 0 || c->kind > 2) return "kind must be 0 (vision), 1 (text) or 2 (BERT text)";
     if (c->width != 128 && c->width != 512 && c->width != 768 && c->width != 1024) return "width must be 128, 512, 768 or 1024";
     if (c->heads * 64 != c->width) return "heads must equal width / 64 (head dim 64)";
     if (c->layers < 1 || c->layers > 64) return "layers outside [1,64]";
@@ -72,8 +76,17 @@ static Layout make_layout(const mmr_tower_cfg &c)
         put(L.global[MMR_P_TOK_EMB], (size_t)c.vocab * d * 2);
         put(L.global[MMR_P_POS], T * d * 4);
     }
-    put(L.global[MMR_P_LN_FINAL_W], d * 4);
-    put(L.global[MMR_P_LN_FINAL_B], d * 4);
+    if (c.kind == 2) {
+        put(L.global[MMR_P_TYPE_EMB], 2 * d * 4);
+        put(L.global[MMR_P_LN_PRE_W], d * 4);      // embeddings LayerNorm
+        put(L.global[MMR_P_LN_PRE_B], d * 4);
+        put(L.global[MMR_P_POOL_W], d * d * 2);
+        put(L.global[MMR_P_POOL_B], d * 4);
+        put(L.global[MMR_P_PROJ_B], E * 4);
+    } else {
+        put(L.global[MMR_P_LN_FINAL_W], d * 4);
+        put(L.global[MMR_P_LN_FINAL_B], d * 4);
+    }
     put(L.global[MMR_P_PROJ], E * d * 2);
     const size_t l0 = off;
     put(L.layer0[MMR_P_LN1_W], d * 4);
@@ -196,6 +209,7 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
                                  void *stream)
 {
     MMR_CHECK_ARG(t != nullptr, "mmr_tower_forward: null tower");
+    MMR_CHECK_ARG(t->cfg.kind != 2, "mmr_tower_forward: BERT towers run through mmr_bert_forward");
     const mmr_tower_cfg &c = t->cfg;
     MMR_CHECK_ARG(B >= 0 && B <= 65535, "mmr_tower_forward: batch %d outside [0,65535]", B);
     if (B == 0) return MMR_OK;
@@ -266,11 +280,93 @@ extern "C" int mmr_text_encode(mmr_tower *t, const int32_t *ids, int N, void *ou
     return mmr_tower_forward(t, ids, MMR_F32, N, out, out_dtype, normalize, -1, nullptr, workspace, workspace_bytes, stream);
 }
 
+// ---- BERT-style text classifier (Taiyi)
+namespace {
+struct BertWs {
+    int M, Mpad, Npad;
+    size_t off_h, off_x, off_big, off_xc, off_xp, off_feat, total;
+};
+BertWs plan_bert(const mmr_tower_cfg &c, int N, int T)
+{
+    BertWs p{};
+    p.M = N * T;
+    p.Mpad = round_up(p.M, p.M >= 4096 ? 256 : 128);
+    p.Npad = round_up(N, 128);
+    const size_t d = c.width;
+    const size_t wide = (size_t)(c.mlp > 3 * c.width ? c.mlp : 3 * c.width);
+    size_t off = 0;
+    auto put = [&](size_t &o, size_t bytes) { o = off; off += align_up(bytes, 256); };
+    put(p.off_h, (size_t)p.Mpad * d * 4);
+    put(p.off_x, (size_t)p.Mpad * d * 2);
+    put(p.off_big, (size_t)p.Mpad * wide * 2);
+    put(p.off_xc, (size_t)p.Npad * d * 2);
+    put(p.off_xp, (size_t)p.Npad * d * 2);
+    put(p.off_feat, (size_t)p.Npad * c.embed_dim * 4);
+    p.total = off;
+    return p;
+}
+}  // namespace
+
+extern "C" size_t mmr_bert_workspace_bytes(const mmr_tower *t, int N, int T)
+{
+    if (!t || t->cfg.kind != 2 || N < 1 || T < 1 || T > t->cfg.tokens) return 0;
+    return plan_bert(t->cfg, N, T).total;
+}
+
+extern "C" int mmr_bert_forward(mmr_tower *t, const int32_t *ids, int N, int T, void *out, mmr_dtype out_dtype,
+                                int normalize, int tap_after, float *tap, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    MMR_CHECK_ARG(t && t->cfg.kind == 2, "mmr_bert_forward: not a BERT tower");
+    const mmr_tower_cfg &c = t->cfg;
+    MMR_CHECK_ARG(N >= 0 && N <= 65535, "mmr_bert_forward: batch %d outside [0,65535]", N);
+    if (N == 0) return MMR_OK;
+    MMR_CHECK_ARG(T >= 1 && T <= c.tokens, "mmr_bert_forward: sequence length %d outside [1,%d]", T, c.tokens);
+    MMR_CHECK_ARG(ids && out && workspace, "mmr_bert_forward: null pointer");
+    MMR_CHECK_ARG(out_dtype == MMR_F32 || out_dtype == MMR_BF16, "mmr_bert_forward: out dtype %d", (int)out_dtype);
+    MMR_CHECK_ARG(((uintptr_t)workspace & 255) == 0, "mmr_bert_forward: workspace must be 256-byte aligned");
+    MMR_CHECK_ARG(tap_after >= -1 && tap_after < c.layers, "mmr_bert_forward: tap_after %d outside [-1,%d)", tap_after, c.layers);
+    const BertWs p = plan_bert(c, N, T);
+    if (workspace_bytes < p.total) { set_error("mmr_bert_forward: workspace %zu < required %zu", workspace_bytes, p.total); return MMR_ENOSPC; }
+
+    hipStream_t st = (hipStream_t)stream;
+    char *ws = (char *)workspace;
+    float *h = (float *)(ws + p.off_h);
+    bf16_t *x = (bf16_t *)(ws + p.off_x);
+    bf16_t *big = (bf16_t *)(ws + p.off_big);
+    bf16_t *xc = (bf16_t *)(ws + p.off_xc);
+    bf16_t *xp = (bf16_t *)(ws + p.off_xp);
+    float *feat = (float *)(ws + p.off_feat);
+    const int d = c.width, E = c.embed_dim, m = c.mlp;
+    const size_t hbytes = (size_t)p.M * d * sizeof(float);
+    int rc;
+
+    if ((rc = launch_embed_bert(ids, t->g<bf16_t>(MMR_P_TOK_EMB), t->g<float>(MMR_P_POS), t->g<float>(MMR_P_TYPE_EMB),
+                                t->g<float>(MMR_P_LN_PRE_W), t->g<float>(MMR_P_LN_PRE_B), h, x, N, T, d, c.vocab, c.ln_eps, st))) return rc;
+    if (tap && tap_after == -1) MMR_CHECK_HIP(hipMemcpyAsync(tap, h, hbytes, hipMemcpyDeviceToDevice, st));
+    // post-LN blocks (modeling_bert.py:139-204,282-352): x = LN(x + Attn(x)); x = LN(x + FFN(x))
+    for (int i = 0; i < c.layers; ++i) {
+        if ((rc = launch_gemm(EPI_BIAS_BF16, x, t->l<bf16_t>(MMR_P_QKV_W, i), p.Mpad, 3 * d, d, t->l<float>(MMR_P_QKV_B, i), big, st))) return rc;
+        if ((rc = launch_attention(big, x, N, T, c.heads, d, 0, st))) return rc;
+        if ((rc = launch_gemm(EPI_BIAS_RESID_F32, x, t->l<bf16_t>(MMR_P_OUT_W, i), p.Mpad, d, d, t->l<float>(MMR_P_OUT_B, i), h, st))) return rc;
+        if ((rc = launch_layernorm_inplace(h, t->l<float>(MMR_P_LN1_W, i), t->l<float>(MMR_P_LN1_B, i), x, p.M, d, c.ln_eps, st))) return rc;
+        if ((rc = launch_gemm(EPI_BIAS_GELU_ERF_BF16, x, t->l<bf16_t>(MMR_P_FC1_W, i), p.Mpad, m, d, t->l<float>(MMR_P_FC1_B, i), big, st))) return rc;
+        if ((rc = launch_gemm(EPI_BIAS_RESID_F32, big, t->l<bf16_t>(MMR_P_FC2_W, i), p.Mpad, d, m, t->l<float>(MMR_P_FC2_B, i), h, st))) return rc;
+        if ((rc = launch_layernorm_inplace(h, t->l<float>(MMR_P_LN2_W, i), t->l<float>(MMR_P_LN2_B, i), x, p.M, d, c.ln_eps, st))) return rc;
+        if (tap && tap_after == i) MMR_CHECK_HIP(hipMemcpyAsync(tap, h, hbytes, hipMemcpyDeviceToDevice, st));
+    }
+    // pooler tanh(dense(first token)) -> classifier (modeling_bert.py:451-464; BertForSequenceClassification)
+    if ((rc = launch_gather_first_rows(x, xc, N, T, d, st))) return rc;
+    if ((rc = launch_gemm(EPI_BIAS_TANH_BF16, xc, t->g<bf16_t>(MMR_P_POOL_W), p.Npad, d, d, t->g<float>(MMR_P_POOL_B), xp, st))) return rc;
+    if ((rc = launch_gemm(EPI_BIAS_F32, xp, t->g<bf16_t>(MMR_P_PROJ), p.Npad, E, d, t->g<float>(MMR_P_PROJ_B), feat, st))) return rc;
+    return launch_finish(feat, out, out_dtype, N, E, normalize, st);
+}
+
 // ---- kernel-level test hooks
 extern "C" int mmr_debug_gemm(int epi, const void *A, const void *W, int M, int N, int K, const float *bias, void *out,
                               void *stream)
 {
-    MMR_CHECK_ARG(epi >= 0 && epi <= 3 && A && W && out && (bias || epi == 3), "mmr_debug_gemm: bad argument");
+    MMR_CHECK_ARG(epi >= 0 && epi <= 6 && A && W && out && (bias || epi == 3), "mmr_debug_gemm: bad argument");
     return launch_gemm(epi, (const bf16_t *)A, (const bf16_t *)W, M, N, K, bias, out, (hipStream_t)stream);
 }
 

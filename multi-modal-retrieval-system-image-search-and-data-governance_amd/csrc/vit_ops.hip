@@ -136,6 +136,67 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     for (int j = 0; j < VPL; ++j) x[(size_t)row * d + j * 64 + lane] = f32_to_bf16(v[j]);
 }
 
+// BERT embeddings (transformers/models/bert/modeling_bert.py:53-108): word[ids] + type[0] + pos[t] -> LayerNorm
+// -> h (fp32) and x = bf16(h)
+template <int VPL>
+__global__ __launch_bounds__(256) void embed_bert_kernel(const int32_t *__restrict__ ids, const bf16_t *__restrict__ tok,
+                                                         const float *__restrict__ pos, const float *__restrict__ type0,
+                                                         const float *__restrict__ lw, const float *__restrict__ lb,
+                                                         float *__restrict__ h, bf16_t *__restrict__ x, int Nb, int T,
+                                                         int d, int vocab, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)Nb * T) return;
+    const int t = (int)(row % T);
+    int id = ids[row];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    float v[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int col = j * 64 + lane;
+        // same association as HF: (word + type) + position
+        v[j] = (bf16_to_f32(tok[(size_t)id * d + col]) + type0[col]) + pos[(size_t)t * d + col];
+    }
+    ln_row<VPL>(v, lw, lb, lane, d, eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        h[(size_t)row * d + j * 64 + lane] = v[j];
+        x[(size_t)row * d + j * 64 + lane] = f32_to_bf16(v[j]);
+    }
+}
+
+// post-LN blocks (BERT): h = LN(h) in place, x = bf16(h)
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_inplace_kernel(float *__restrict__ h, const float *__restrict__ w,
+                                                                const float *__restrict__ b, bf16_t *__restrict__ x,
+                                                                int64_t rows, int d, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) v[j] = h[(size_t)row * d + j * 64 + lane];
+    ln_row<VPL>(v, w, b, lane, d, eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        h[(size_t)row * d + j * 64 + lane] = v[j];
+        x[(size_t)row * d + j * 64 + lane] = f32_to_bf16(v[j]);
+    }
+}
+
+// xc[n] = x[n*T]  (first token of every sequence, bf16 copy for the BERT pooler)
+__global__ __launch_bounds__(256) void gather_first_rows_kernel(const bf16_t *__restrict__ x, bf16_t *__restrict__ xc, int Nb,
+                                                                int T, int d)
+{
+    const int chunks = d / 8;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= Nb * chunks) return;
+    const int n = id / chunks, c = id % chunks;
+    *reinterpret_cast<uint4 *>(xc + (size_t)n * d + c * 8) = *reinterpret_cast<const uint4 *>(x + (size_t)n * T * d + c * 8);
+}
+
 // pooled rows: vision -> token 0 of each image; text -> first position of the largest id (EOT).
 // xc_bf16[n] = LN(h[n*T + pick])
 template <int VPL>
@@ -520,6 +581,35 @@ int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const flo
     ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)((Nb + 3) / 4));
     MMR_VPL_SWITCH(d, hipLaunchKernelGGL(pool_ln_kernel<VPL>, grid, dim3(256), 0, st, h, ids, w, b, xc, Nb, T, d, eps));
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_embed_bert(const int32_t *ids, const bf16_t *tok, const float *pos, const float *type0, const float *lw,
+                      const float *lb, float *h, bf16_t *x, int Nb, int T, int d, int vocab, float eps, hipStream_t st)
+{
+    ProfScope prof(MMR_PROF_ROWWISE, st);
+    const dim3 grid((unsigned)(((int64_t)Nb * T + 3) / 4));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_bert_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, type0, lw, lb, h, x, Nb, T, d, vocab, eps));
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_layernorm_inplace(float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps,
+                             hipStream_t st)
+{
+    ProfScope prof(MMR_PROF_ROWWISE, st);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(layernorm_inplace_kernel<VPL>, grid, dim3(256), 0, st, h, w, b, x, rows, d, eps));
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+int launch_gather_first_rows(const bf16_t *x, bf16_t *xc, int Nb, int T, int d, hipStream_t st)
+{
+    ProfScope prof(MMR_PROF_ROWWISE, st);
+    const int total = Nb * (d / 8);
+    hipLaunchKernelGGL(gather_first_rows_kernel, dim3((total + 255) / 256), dim3(256), 0, st, x, xc, Nb, T, d);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }

@@ -91,3 +91,40 @@ def make_clip_weights(cfg: ClipConfig, seed: int = 0) -> Dict[str, torch.Tensor]
     w.update(make_text_weights(cfg.text, seed))
     w["logit_scale"] = torch.tensor(cfg.logit_scale_init, dtype=torch.float32)
     return w
+
+
+def make_bert_weights(cfg, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded weights for the BERT-style text classifier (names b.*; std 0.02 like BertPreTrainedModel
+    _init_weights, with perturbed LayerNorm / bias tensors so they are exercised).
+
+      b.tok[V,d] b.pos[P,d] b.type[2,d] b.ln_emb.{w,b}
+      b.l{i}.qkv.{w[3d,d],b} b.l{i}.out.{w,b} b.l{i}.ln1.{w,b}   (ln1 = attention-output LayerNorm)
+      b.l{i}.fc1.{w[m,d],b} b.l{i}.fc2.{w[d,m],b} b.l{i}.ln2.{w,b} (ln2 = output LayerNorm)
+      b.pool.{w[d,d],b} b.cls.{w[E,d],b}
+    """
+    d, m, E = cfg.width, cfg.mlp, cfg.embed_dim
+    w: Dict[str, torch.Tensor] = {}
+    w["b.tok"] = _randn("b.tok", (cfg.vocab, d), 0.02, seed)
+    w["b.pos"] = _randn("b.pos", (cfg.max_positions, d), 0.02, seed)
+    w["b.type"] = _randn("b.type", (2, d), 0.02, seed)
+    w["b.ln_emb.w"] = _randn("b.ln_emb.w", (d,), 0.1, seed, mean=1.0)
+    w["b.ln_emb.b"] = _randn("b.ln_emb.b", (d,), 0.05, seed)
+    for i in range(cfg.layers):
+        p = f"b.l{i}"
+        w[f"{p}.qkv.w"] = _randn(f"{p}.qkv.w", (3 * d, d), 0.02, seed)
+        w[f"{p}.qkv.b"] = _randn(f"{p}.qkv.b", (3 * d,), 0.02, seed)
+        w[f"{p}.out.w"] = _randn(f"{p}.out.w", (d, d), 0.02, seed)
+        w[f"{p}.out.b"] = _randn(f"{p}.out.b", (d,), 0.02, seed)
+        w[f"{p}.ln1.w"] = _randn(f"{p}.ln1.w", (d,), 0.1, seed, mean=1.0)
+        w[f"{p}.ln1.b"] = _randn(f"{p}.ln1.b", (d,), 0.05, seed)
+        w[f"{p}.fc1.w"] = _randn(f"{p}.fc1.w", (m, d), 0.02, seed)
+        w[f"{p}.fc1.b"] = _randn(f"{p}.fc1.b", (m,), 0.02, seed)
+        w[f"{p}.fc2.w"] = _randn(f"{p}.fc2.w", (d, m), 0.02, seed)
+        w[f"{p}.fc2.b"] = _randn(f"{p}.fc2.b", (d,), 0.02, seed)
+        w[f"{p}.ln2.w"] = _randn(f"{p}.ln2.w", (d,), 0.1, seed, mean=1.0)
+        w[f"{p}.ln2.b"] = _randn(f"{p}.ln2.b", (d,), 0.05, seed)
+    w["b.pool.w"] = _randn("b.pool.w", (d, d), 0.02, seed)
+    w["b.pool.b"] = _randn("b.pool.b", (d,), 0.02, seed)
+    w["b.cls.w"] = _randn("b.cls.w", (E, d), 0.02, seed)
+    w["b.cls.b"] = _randn("b.cls.b", (E,), 0.02, seed)
+    return w

@@ -87,3 +87,47 @@ def hf_image_features(model, pixels):
 def hf_text_features(model, ids):
     out = model.get_text_features(input_ids=ids)
     return out.pooler_output if hasattr(out, "pooler_output") else out
+
+
+def build_hf_bert(cfg, w):
+    """transformers.BertForSequenceClassification from a LOCAL config + this repo's seeded weights."""
+    from transformers import BertConfig, BertForSequenceClassification
+
+    hc = BertConfig(vocab_size=cfg.vocab, hidden_size=cfg.width, num_hidden_layers=cfg.layers,
+                    num_attention_heads=cfg.heads, intermediate_size=cfg.mlp, hidden_act="gelu",
+                    max_position_embeddings=cfg.max_positions, type_vocab_size=2, layer_norm_eps=cfg.ln_eps,
+                    num_labels=cfg.embed_dim, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    hc._attn_implementation = "eager"
+    model = BertForSequenceClassification(hc).eval()
+    d = cfg.width
+    sd = {
+        "bert.embeddings.word_embeddings.weight": w["b.tok"],
+        "bert.embeddings.position_embeddings.weight": w["b.pos"],
+        "bert.embeddings.token_type_embeddings.weight": w["b.type"],
+        "bert.embeddings.LayerNorm.weight": w["b.ln_emb.w"],
+        "bert.embeddings.LayerNorm.bias": w["b.ln_emb.b"],
+        "bert.pooler.dense.weight": w["b.pool.w"], "bert.pooler.dense.bias": w["b.pool.b"],
+        "classifier.weight": w["b.cls.w"], "classifier.bias": w["b.cls.b"],
+    }
+    for i in range(cfg.layers):
+        hp, p = f"bert.encoder.layer.{i}", f"b.l{i}"
+        qw, kw, vw = w[f"{p}.qkv.w"].split(d, dim=0)
+        qb, kb, vb = w[f"{p}.qkv.b"].split(d, dim=0)
+        sd[f"{hp}.attention.self.query.weight"], sd[f"{hp}.attention.self.query.bias"] = qw, qb
+        sd[f"{hp}.attention.self.key.weight"], sd[f"{hp}.attention.self.key.bias"] = kw, kb
+        sd[f"{hp}.attention.self.value.weight"], sd[f"{hp}.attention.self.value.bias"] = vw, vb
+        sd[f"{hp}.attention.output.dense.weight"] = w[f"{p}.out.w"]
+        sd[f"{hp}.attention.output.dense.bias"] = w[f"{p}.out.b"]
+        sd[f"{hp}.attention.output.LayerNorm.weight"] = w[f"{p}.ln1.w"]
+        sd[f"{hp}.attention.output.LayerNorm.bias"] = w[f"{p}.ln1.b"]
+        sd[f"{hp}.intermediate.dense.weight"] = w[f"{p}.fc1.w"]
+        sd[f"{hp}.intermediate.dense.bias"] = w[f"{p}.fc1.b"]
+        sd[f"{hp}.output.dense.weight"] = w[f"{p}.fc2.w"]
+        sd[f"{hp}.output.dense.bias"] = w[f"{p}.fc2.b"]
+        sd[f"{hp}.output.LayerNorm.weight"] = w[f"{p}.ln2.w"]
+        sd[f"{hp}.output.LayerNorm.bias"] = w[f"{p}.ln2.b"]
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "position_ids" not in m and "token_type_ids" not in m]
+    if missing or unexpected:
+        raise RuntimeError(f"HF BERT state_dict mismatch: missing={missing} unexpected={unexpected}")
+    return model

@@ -146,6 +146,34 @@ def search_golden():
     print("wrote", fn, os.path.getsize(fn), "bytes")
 
 
+@torch.no_grad()
+def bert_golden(name, n_txt, T, with_stages):
+    from mmr_amd.config import get_bert_config
+    from oracle import bert_ref
+    cfg = get_bert_config(name)
+    w = weights.make_bert_weights(cfg, seed=0)
+    hf = hf_adapter.build_hf_bert(cfg, w)
+    g = torch.Generator().manual_seed(7)
+    ids = torch.randint(1, cfg.vocab, (n_txt, T), generator=g, dtype=torch.int32)
+    ids[:, 0] = 101 % cfg.vocab                      # [CLS]-like first token
+    ids[1:, T - 3:] = 0                              # trailing [PAD]s: attended to, as in the reference's call
+    out_hf = hf(ids.long())                          # ids only, exactly like code/test_taiyi.py:24
+    st = {}
+    out_or = bert_ref.bert_logits(w, cfg, ids, stages=st)
+    d = _maxdiff(out_hf.logits, out_or)
+    print(f"[{name}] BERT logits oracle-vs-HF max|diff| = {d:.3e} (|f|~{float(out_hf.logits.norm(dim=-1).mean()):.2f})")
+    assert d <= 5e-5 * max(1.0, float(out_hf.logits.abs().max())), d
+    out = {"weight_seed": 0, "ids_seed": 7, "n_txt": n_txt, "T": T, "logits": out_hf.logits.numpy()}
+    if with_stages:
+        hs = hf.bert(ids.long(), output_hidden_states=True).hidden_states
+        assert _maxdiff(hs[0], st["embed"]) <= 2e-5 and _maxdiff(hs[1], st["layer0"]) <= 5e-5
+        out["embed"] = hs[0].numpy()
+        out["layer0"] = hs[1].numpy()
+    fn = os.path.join(GOLD, "bert_" + name + ".npz")
+    np.savez_compressed(fn, **out)
+    print("wrote", fn, os.path.getsize(fn), "bytes")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--skip-large", action="store_true", help="skip the ViT-L/14 goldens (slow, ~3 GB RAM)")
@@ -161,6 +189,10 @@ def main():
         encoder_golden("ViT-B/32", 4, 3, with_stages=False)
     if not a.skip_large and a.only in ("", "l14"):
         encoder_golden("ViT-L/14", 1, 2, with_stages=False, with_text=True)
+    if a.only in ("", "bert"):
+        bert_golden("tiny-bert-test", 3, 19, with_stages=True)
+        if not a.skip_large:
+            bert_golden("Taiyi-CLIP-Roberta-large-326M-Chinese", 2, 12, with_stages=False)
     if not a.skip_large and a.only in ("", "l14_336"):
         encoder_golden("ViT-L/14@336px", 1, 0, with_stages=False, with_text=False)
 

@@ -32,7 +32,7 @@ def _cos(a, b):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (1280, 2304, 768), (384, 768, 3072),
                                    (256, 256, 64), (512, 256, 128), (256, 768, 192), (4096, 1024, 256),
                                    (12800, 768, 768)])
-@pytest.mark.parametrize("epi", [0, 1, 2, 3])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_epilogues(L, device, M, N, K, epi):
     g = torch.Generator().manual_seed(M + N + K + epi)
     # asymmetric, non-trivial operands (an A=I / symmetric-B check would hide a transposed write)
@@ -44,9 +44,13 @@ def test_gemm_epilogues(L, device, M, N, K, epi):
         ref = ref + bias
     if epi == 1:
         ref = ref * torch.sigmoid(1.702 * ref)
+    elif epi == 5:
+        ref = torch.nn.functional.gelu(ref)                   # exact (erf) GELU, the BERT activation
+    elif epi == 6:
+        ref = torch.tanh(ref)                                 # BERT pooler
     Ad, Wd, bd = A.to(device), W.to(device), bias.to(device)
     st = L.stream_ptr(device)
-    if epi in (0, 1):
+    if epi in (0, 1, 5, 6):
         out = torch.empty(M, N, dtype=torch.bfloat16, device=device)
         L.check(L.lib().mmr_debug_gemm(epi, Ad.data_ptr(), Wd.data_ptr(), M, N, K, bd.data_ptr(), out.data_ptr(), st))
         got = out.float().cpu()
@@ -59,7 +63,8 @@ def test_gemm_epilogues(L, device, M, N, K, epi):
         tol = 2e-4 * max(1.0, ref.abs().max().item())
     else:
         out = torch.empty(M, N, dtype=torch.float32, device=device)
-        L.check(L.lib().mmr_debug_gemm(epi, Ad.data_ptr(), Wd.data_ptr(), M, N, K, 0, out.data_ptr(), st))
+        L.check(L.lib().mmr_debug_gemm(epi, Ad.data_ptr(), Wd.data_ptr(), M, N, K, bd.data_ptr() if epi == 4 else 0,
+                                       out.data_ptr(), st))
         got = out.cpu()
         tol = 2e-4 * max(1.0, ref.abs().max().item())
     err = (got - ref).abs().max().item()
