@@ -302,16 +302,31 @@ def load(name: str = "ViT-B/32", device: Union[str, torch.device] = "cuda", jit:
     return model, _preprocess_factory(cfg.vision.image_size, model.device)
 
 
+_bpe_cache = {}
+
+
 def tokenize(texts: Union[str, List[str], torch.Tensor, List[List[int]]], context_length: int = _CONTEXT,
-             truncate: bool = False) -> torch.Tensor:
+             truncate: bool = False, bpe_path: Optional[str] = None) -> torch.Tensor:
     """``clip.tokenize`` surface -> IntTensor[N, context_length].
 
-    The BPE vocabulary file ships with the ``clip`` package, which is absent offline (SURVEY.md 8f
-    row 4), so strings cannot be encoded here: pass token ids (one list per text, SOT..EOT, unpadded
-    or padded); they are zero-padded to ``context_length`` like the original.  Over-long inputs raise
-    RuntimeError exactly as ``clip.tokenize`` does unless ``truncate``."""
+    Strings are encoded with the CLIP byte-level BPE (tokenizer.ClipBPETokenizer) when the merge table is
+    supplied -- ``bpe_path`` or the ``MMR_CLIP_BPE`` environment variable pointing at the ``clip`` package's
+    ``bpe_simple_vocab_16e6.txt.gz`` (or an HF ``merges.txt``).  That file is not reachable offline
+    (SURVEY.md 8f row 4); without it strings raise RuntimeError and token ids are accepted instead (one list
+    per text, SOT..EOT, unpadded or padded), zero-padded to ``context_length`` like the original.  Over-long
+    inputs raise RuntimeError exactly as ``clip.tokenize`` does unless ``truncate``."""
     if isinstance(texts, str) or (isinstance(texts, (list, tuple)) and texts and isinstance(texts[0], str)):
-        raise RuntimeError("BPE vocabulary is not available offline; pass token ids instead of strings")
+        import os
+
+        path = bpe_path or os.environ.get("MMR_CLIP_BPE")
+        if not path:
+            raise RuntimeError("BPE vocabulary is not available offline; pass token ids instead of strings, or give "
+                               "bpe_path= / MMR_CLIP_BPE pointing at bpe_simple_vocab_16e6.txt.gz")
+        if path not in _bpe_cache:
+            from .tokenizer import ClipBPETokenizer
+
+            _bpe_cache[path] = ClipBPETokenizer(path)
+        return _bpe_cache[path](texts, context_length, truncate)
     if isinstance(texts, torch.Tensor):
         rows = texts.tolist() if texts.dim() == 2 else [texts.tolist()]
     else:

@@ -111,6 +111,14 @@ def test_tokenize_surface():
     assert t.shape == (1, 77) and t[0, -1] == 89
 
 
+def test_tokenize_strings_with_a_merge_table(tmp_path):
+    from mmr_amd.clip import tokenize
+    p = tmp_path / "merges.txt"
+    p.write_text("#version: 0.2\nc a\nca t</w>\n")
+    out = tokenize(["cat", "a cat"], bpe_path=str(p))
+    assert out.shape == (2, 77) and out[0, 0] == out[1, 0] and (out[0] != 0).sum() == 3   # SOT cat EOT
+
+
 def test_no_gpu_means_loud_failure():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
