@@ -187,6 +187,9 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
 #ifndef MMR_GEMM_PHASES
 #define MMR_GEMM_PHASES 2
 #endif
+#ifndef MMR_GEMM_SPLIT_STAGE
+#define MMR_GEMM_SPLIT_STAGE 0   // measured: issuing half of the LDS-DMA inside the COMPUTE segment is 8% SLOWER
+#endif
 constexpr int BM2 = 256, BN2 = 256;
 constexpr int GEMM2_THREADS = 512;
 constexpr int HALF_BYTES = 128 * BK * 2;            // 16 KiB: 128 rows x 64 bf16
@@ -312,20 +315,39 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         mma(1, 0);
         __builtin_amdgcn_s_barrier();
 #else
-        // Two phases per K-tile, 32 MFMAs each (fewer, longer segments: less barrier overhead).
+        // Two phases per K-tile, 32 MFMAs each (fewer, longer segments: less barrier overhead).  Both
+        // half-tile stages of a phase are issued in its LOAD segment; MMR_GEMM_SPLIT_STAGE=1 moves one of
+        // them between the two MFMA clusters of the COMPUTE segment (an A/B knob: measured 8% slower --
+        // the main loop already runs within ~10% of the MFMA issue rate at the sustained clock).
         // phase A: quadrants (0,0) (0,1): reads W both n-halves + A m-half 0; stages A0, A1 of tile kt+1
         read_w(0); read_w(1); read_a(0);
-        stage(kt + 1, 2); stage(kt + 1, 3);
+        stage(kt + 1, 2);
+#if !MMR_GEMM_SPLIT_STAGE
+        stage(kt + 1, 3);
+#endif
         MMR_LOAD_DONE();
-        mma(0, 0); mma(0, 1);
+        mma(0, 0);
+#if MMR_GEMM_SPLIT_STAGE
+        stage(kt + 1, 3);
+#endif
+        mma(0, 1);
         __builtin_amdgcn_s_barrier();
         // phase B: quadrants (1,1) (1,0): reads A m-half 1; stages W0, W1 of tile kt+2 (W of tile kt was
         // last read in phase A); retires tile kt+1's half-tiles (youngest staged in phase A of this tile)
         read_a(1);
-        stage(kt + 2, 0); stage(kt + 2, 1);
+        stage(kt + 2, 0);
+#if MMR_GEMM_SPLIT_STAGE
+        if (kt + 2 < nkt) wait_vmcnt<2>(); else wait_vmcnt<0>();
+#else
+        stage(kt + 2, 1);
         if (kt + 2 < nkt) wait_vmcnt<4>(); else wait_vmcnt<0>();
+#endif
         MMR_LOAD_DONE();
-        mma(1, 1); mma(1, 0);
+        mma(1, 1);
+#if MMR_GEMM_SPLIT_STAGE
+        stage(kt + 2, 1);
+#endif
+        mma(1, 0);
         __builtin_amdgcn_s_barrier();
 #endif
     }
