@@ -165,6 +165,18 @@ int mmr_preprocess_image(const uint8_t *img, int H, int W, int S, int row0, int 
                          float mean0, float mean1, float mean2, float std0, float std1, float std2, uint8_t *tmp,
                          void *out, mmr_dtype out_dtype, uint8_t *out_u8, void *stream);
 
+/* Batched form: B images of different sizes in one launch pair.  `desc` is a DEVICE array of B
+ * descriptors; tables/pointers as in mmr_preprocess_image; out[B,3,S,S].  max_rows = max over images of
+ * `rows` (sizes the grid). */
+typedef struct {
+    const uint8_t *img;
+    const int32_t *hbounds, *hcoeffs, *vbounds, *vcoeffs;
+    uint8_t *tmp;
+    int32_t H, W, row0, rows, hk, vk;
+} mmr_preprocess_desc;
+int mmr_preprocess_batch(const void *desc, int B, int S, int max_rows, float mean0, float mean1, float mean2,
+                         float std0, float std1, float std2, void *out, mmr_dtype out_dtype, void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Launch profiler (measurement aid for bench.py): HIP event pairs around every kernel launch of a
  * class, recorded on the launch stream.  Off by default.

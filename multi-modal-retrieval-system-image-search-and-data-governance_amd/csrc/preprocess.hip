@@ -77,9 +77,89 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t *__r
     }
 }
 
+// ---- batched form: one launch pair for B images of different sizes, driven by a descriptor table
+struct PreDesc {            // mirrors mmr_preprocess_desc in include/mmr.h
+    const uint8_t *img;     // uint8 RGB [H,W,3]
+    const int32_t *hbounds, *hcoeffs, *vbounds, *vcoeffs;
+    uint8_t *tmp;           // uint8 [rows,S,3] scratch of this image
+    int32_t H, W, row0, rows, hk, vk;
+};
+
+__global__ __launch_bounds__(256) void resample_h_batch_kernel(const PreDesc *__restrict__ desc, int S, int max_rows)
+{
+    const PreDesc d = desc[blockIdx.y];
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= d.rows * S) return;
+    const int x = id % S, r = id / S;
+    const int2 b = reinterpret_cast<const int2 *>(d.hbounds)[x];
+    const int *k = d.hcoeffs + (size_t)x * d.hk;
+    const uint8_t *p = d.img + ((size_t)(d.row0 + r) * d.W + b.x) * 3;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int t = 0; t < b.y; ++t) {
+        const int kk = k[t];
+        a0 += p[3 * t + 0] * kk; a1 += p[3 * t + 1] * kk; a2 += p[3 * t + 2] * kk;
+    }
+    uint8_t *o = d.tmp + (size_t)id * 3;
+    o[0] = (uint8_t)clip8(a0); o[1] = (uint8_t)clip8(a1); o[2] = (uint8_t)clip8(a2);
+}
+
+template <typename TOUT>
+__global__ __launch_bounds__(256) void resample_v_norm_batch_kernel(const PreDesc *__restrict__ desc, int S, float m0,
+                                                                    float m1, float m2, float s0, float s1, float s2,
+                                                                    TOUT *__restrict__ out)
+{
+    const PreDesc d = desc[blockIdx.y];
+    const int id = blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= S * S) return;
+    const int x = id % S, y = id / S;
+    const int2 b = reinterpret_cast<const int2 *>(d.vbounds)[y];
+    const int *k = d.vcoeffs + (size_t)y * d.vk;
+    const uint8_t *p = d.tmp + ((size_t)(b.x - d.row0) * S + x) * 3;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int t = 0; t < b.y; ++t) {
+        const int kk = k[t];
+        const uint8_t *q = p + (size_t)t * S * 3;
+        a0 += q[0] * kk; a1 += q[1] * kk; a2 += q[2] * kk;
+    }
+    const float f0 = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(a0), 255.0f), m0), s0);
+    const float f1 = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(a1), 255.0f), m1), s1);
+    const float f2 = __fdiv_rn(__fsub_rn(__fdiv_rn((float)clip8(a2), 255.0f), m2), s2);
+    const size_t plane = (size_t)S * S;
+    TOUT *o = out + (size_t)blockIdx.y * 3 * plane;
+    if constexpr (sizeof(TOUT) == 2) {
+        ((bf16_t *)o)[id] = f32_to_bf16(f0); ((bf16_t *)o)[plane + id] = f32_to_bf16(f1); ((bf16_t *)o)[2 * plane + id] = f32_to_bf16(f2);
+    } else {
+        ((float *)o)[id] = f0; ((float *)o)[plane + id] = f1; ((float *)o)[2 * plane + id] = f2;
+    }
+}
+
 }  // namespace mmr
 
 using namespace mmr;
+
+extern "C" int mmr_preprocess_batch(const void *desc, int B, int S, int max_rows, float mean0, float mean1, float mean2,
+                                    float std0, float std1, float std2, void *out, mmr_dtype out_dtype, void *stream)
+{
+    MMR_CHECK_ARG(desc && out, "mmr_preprocess_batch: null pointer");
+    MMR_CHECK_ARG(B >= 0 && B <= 65535 && S >= 1 && S <= 4096 && max_rows >= 1, "mmr_preprocess_batch: bad size B=%d S=%d max_rows=%d", B, S, max_rows);
+    MMR_CHECK_ARG(out_dtype == MMR_F32 || out_dtype == MMR_BF16, "mmr_preprocess_batch: out dtype %d", (int)out_dtype);
+    MMR_CHECK_ARG(std0 != 0.f && std1 != 0.f && std2 != 0.f, "mmr_preprocess_batch: zero std");
+    MMR_CHECK_ARG(sizeof(PreDesc) == 72, "mmr_preprocess_batch: descriptor layout drifted");
+    if (B == 0) return MMR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(MMR_PROF_ROWWISE, st);
+    const PreDesc *d = (const PreDesc *)desc;
+    hipLaunchKernelGGL(resample_h_batch_kernel, dim3(((size_t)max_rows * S + 255) / 256, B), dim3(256), 0, st, d, S, max_rows);
+    MMR_CHECK_LAUNCH();
+    if (out_dtype == MMR_BF16)
+        hipLaunchKernelGGL(resample_v_norm_batch_kernel<bf16_t>, dim3((S * S + 255) / 256, B), dim3(256), 0, st, d, S, mean0,
+                           mean1, mean2, std0, std1, std2, (bf16_t *)out);
+    else
+        hipLaunchKernelGGL(resample_v_norm_batch_kernel<float>, dim3((S * S + 255) / 256, B), dim3(256), 0, st, d, S, mean0,
+                           mean1, mean2, std0, std1, std2, (float *)out);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
 
 extern "C" int mmr_preprocess_image(const uint8_t *img, int H, int W, int S, int row0, int rows, const int32_t *hbounds,
                                     const int32_t *hcoeffs, int hk, const int32_t *vbounds, const int32_t *vcoeffs,

@@ -137,12 +137,44 @@ def preprocess_image(img_u8: torch.Tensor, n_px: int = 224, out: torch.Tensor = 
     return (out, u8) if return_u8 else out
 
 
-def preprocess_batch(images: Sequence[torch.Tensor], n_px: int = 224, out_dtype: torch.dtype = torch.float32):
-    """A list of uint8 [H_i,W_i,3] GPU tensors (any sizes) -> [B,3,n_px,n_px]."""
+def preprocess_batch(images: Sequence[torch.Tensor], n_px: int = 224, out_dtype: torch.dtype = torch.float32,
+                     mean: Sequence[float] = CLIP_MEAN, std: Sequence[float] = CLIP_STD) -> torch.Tensor:
+    """A list of uint8 [H_i,W_i,3] GPU tensors (any sizes) -> [B,3,n_px,n_px] in ONE launch pair
+    (mmr_preprocess_batch): per-image descriptors (pointers, geometry, coefficient tables) are built on
+    the host and uploaded as one small array."""
+    import numpy as np
+
     if not images:
         raise ValueError("empty batch")
     dev = images[0].device
-    out = torch.empty(len(images), 3, n_px, n_px, dtype=out_dtype, device=dev)
-    for i, im in enumerate(images):
-        preprocess_image(im, n_px, out=out[i], out_dtype=out_dtype)
+    imgs, tabs, rows = [], [], []
+    for im in images:
+        if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+            raise ValueError(f"expected uint8 [H,W,3] tensors, got {im.dtype} {tuple(im.shape)}")
+        if not im.is_cuda:
+            raise RuntimeError("images must live on the GPU (there is no CPU path)")
+        im = im.contiguous()
+        t = _device_tables(int(im.shape[0]), int(im.shape[1]), n_px, dev)
+        imgs.append(im)
+        tabs.append(t)
+        rows.append(t["row1"] - t["row0"])
+    B = len(imgs)
+    offs = np.concatenate([[0], np.cumsum([r * n_px * 3 for r in rows])]).astype(np.int64)
+    tmp = torch.empty(int(offs[-1]) + 16, dtype=torch.uint8, device=dev)
+    desc = np.zeros((B, 9), dtype=np.int64)              # 6 pointers + 6 int32 packed as 3 int64 = 72 bytes
+    for i, (im, t) in enumerate(zip(imgs, tabs)):
+        desc[i, 0] = im.data_ptr()
+        desc[i, 1], desc[i, 2] = t["hb"].data_ptr(), t["hc"].data_ptr()
+        desc[i, 3], desc[i, 4] = t["vb"].data_ptr(), t["vc"].data_ptr()
+        desc[i, 5] = tmp.data_ptr() + int(offs[i])
+        ints = np.array([im.shape[0], im.shape[1], t["row0"], rows[i], t["hk"], t["vk"]], dtype=np.int32)
+        desc[i, 6:9] = ints.view(np.int64)
+    desc_d = torch.from_numpy(desc).to(dev)
+    out = torch.empty(B, 3, n_px, n_px, dtype=out_dtype, device=dev)
+    L = _lib.lib()
+    _lib.check(L.mmr_preprocess_batch(desc_d.data_ptr(), B, n_px, int(max(rows)), float(mean[0]), float(mean[1]),
+                                      float(mean[2]), float(std[0]), float(std[1]), float(std[2]), out.data_ptr(),
+                                      _lib.dtype_code(out_dtype), _lib.stream_ptr(dev)))
+    # descriptors, tables and images must outlive the launch: tie them to the output's lifetime
+    out._mmr_keepalive = (desc_d, tmp, imgs)
     return out

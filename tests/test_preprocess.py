@@ -78,7 +78,10 @@ def test_preprocess_feeds_encoder(device):
     imgs = [_img(80 + 13 * i, 120 - 7 * i, seed=i) for i in range(5)]
     batch = P.preprocess_batch([torch.from_numpy(a).to(device) for a in imgs], model.input_resolution)
     ref = torch.stack([preprocess_ref.preprocess(a, model.input_resolution) for a in imgs])
-    assert torch.equal(batch.cpu(), ref)
+    assert torch.equal(batch.cpu(), ref)                      # one launch pair for 5 differently sized images
+    big = [_img(h, w, seed=h) for h, w in SIZES]
+    b224 = P.preprocess_batch([torch.from_numpy(a).to(device) for a in big], 224, out_dtype=torch.bfloat16)
+    assert torch.equal(b224.cpu(), torch.stack([preprocess_ref.preprocess(a, 224) for a in big]).bfloat16())
     f = model.encode_image(batch)
     assert f.shape == (5, model.cfg.embed_dim) and torch.isfinite(f).all()
     with pytest.raises(ValueError):
