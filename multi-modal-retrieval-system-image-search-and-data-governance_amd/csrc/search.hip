@@ -207,6 +207,117 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
 }
 
 // ---------------------------------------------------------------------------------------------
+// scan for fp32 galleries (the dtype of the reference's feature caches): same pipeline, 16-row
+// tiles, v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 1/16 of the bf16 MFMA rate -> MFMA-bound).
+// Each wave keeps 16 queries resident (E/4 VGPRs); lane (r, g) owns the 16-byte chunk 4S+g of row r
+// for "super-step" S and feeds its 4 floats to MFMA steps 4S..4S+3 -- a k-permutation shared by
+// both operands, so one conflict-free ds_read_b128 serves four MFMAs.
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_ROWS_F32 = 16;
+
+template <int E>
+struct ScanF32Cfg {
+    static constexpr int SCAN_WAVES = E <= 512 ? 8 : 4;
+    static constexpr int SCAN_THREADS = SCAN_WAVES * 64;
+    static constexpr int QMAX = SCAN_WAVES * 16;
+    static constexpr int CH = E / 4;                       // 16-byte chunks per fp32 row
+    static constexpr int ROWB = E * 4;
+    static constexpr int TILE_BYTES = TILE_ROWS_F32 * ROWB;
+    static constexpr int LOADS = TILE_ROWS_F32 * CH / 64;
+    static constexpr int LPW = LOADS / SCAN_WAVES;
+    static constexpr int SSTEPS = E / 16;                  // super-steps (4 MFMAs each)
+    static_assert(LOADS % SCAN_WAVES == 0 && CH % 16 == 0, "tile geometry");
+};
+
+template <int E>
+__global__ __launch_bounds__(ScanF32Cfg<E>::SCAN_THREADS, ScanF32Cfg<E>::SCAN_WAVES / 4) void scan_f32_kernel(
+    const float *__restrict__ q, const float *__restrict__ gal, int Q, int64_t N, int ntiles, int tpt, int qwaves,
+    int qpad, float *__restrict__ bmax, float *__restrict__ tmax)
+{
+    using C = ScanF32Cfg<E>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int task = blockIdx.x;
+    const int t0 = task * tpt;
+    const int t1 = min(ntiles, t0 + tpt);
+    const bool compute = wave < qwaves;
+
+    float4 bq[C::SSTEPS];     // query (wave*16 + r): floats [16S + 4g, +4)
+    {
+        const int qrow = wave * 16 + r;
+        const bool live = compute && qrow < Q;
+        const float *qp = q + (size_t)(live ? qrow : 0) * E + g * 4;
+#pragma unroll
+        for (int S = 0; S < C::SSTEPS; ++S) {
+            const float4 v = *reinterpret_cast<const float4 *>(qp + S * 16);
+            bq[S] = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    auto stage = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < C::LPW; ++i) {
+            const int instr = wave * C::LPW + i;
+            const int p = instr * 64 + lane;
+            const int row = p / C::CH;
+            const int pos = p % C::CH;
+            const int chunk = (pos & ~15) | ((pos ^ row) & 15);
+            int64_t grow = (int64_t)tile * TILE_ROWS_F32 + row;
+            grow = grow < N ? grow : N - 1;
+            glds16(gal + grow * E + chunk * 4, smem + buf * C::TILE_BYTES + instr * 1024);
+        }
+    };
+    const int rowoff = r * C::ROWB;
+    float task_max = -INFINITY, pend = -INFINITY;
+    int pend_tile = -1;
+    constexpr int PD = SCAN_NBUF - 1;
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+        if (t0 + i < t1) stage(t0 + i, i);
+    int cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        const int younger = min(PD - 1, t1 - 1 - t);
+        if (younger >= 2) wait_vmcnt<2 * C::LPW>();
+        else if (younger == 1) wait_vmcnt<C::LPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (compute && pend_tile >= 0 && g == 0) bmax[(size_t)pend_tile * qpad + wave * 16 + r] = pend;
+        int nxt = cur + PD; nxt = nxt >= SCAN_NBUF ? nxt - SCAN_NBUF : nxt;
+        if (t + PD < t1) stage(t + PD, nxt);
+        if (compute) {
+            const char *tb = smem + cur * C::TILE_BYTES + rowoff;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int S = 0; S < C::SSTEPS; ++S) {
+                const int chunk = 4 * S + g;
+                const int pos = (chunk & ~15) | ((chunk ^ r) & 15);
+                const float4 a = *reinterpret_cast<const float4 *>(tb + pos * 16);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bq[S].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bq[S].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bq[S].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bq[S].w, acc, 0, 0, 0);
+            }
+            // acc[i] = dot(query r, tile row 4*g + i)
+            float m = -INFINITY;
+            const int64_t base = (int64_t)t * TILE_ROWS_F32 + 4 * g;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m = fmaxf(m, base + i < N ? acc[i] : -INFINITY);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            task_max = fmaxf(task_max, m);
+            pend = m;
+            pend_tile = t;
+        }
+        cur = cur + 1 >= SCAN_NBUF ? 0 : cur + 1;
+    }
+    if (compute && g == 0) {
+        if (pend_tile >= 0) bmax[(size_t)pend_tile * qpad + wave * 16 + r] = pend;
+        tmax[(size_t)task * qpad + wave * 16 + r] = task_max;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // exact fp64 dot, shared by finalize / exhaustive / similarity
 // ---------------------------------------------------------------------------------------------
 // A row of E elements is 64 contiguous chunks of PER = E/64 elements.  load_chunk fetches chunk
@@ -493,8 +604,8 @@ __global__ __launch_bounds__(FIN_THREADS) void select_kernel(
 
 template <typename T, int PER>
 __global__ __launch_bounds__(FIN_THREADS) void rescore_kernel(
-    const T *__restrict__ q, const T *__restrict__ gal, int64_t N, const int32_t *__restrict__ sel_tiles,
-    double *__restrict__ cand /*[Q][KS_MAX*32]*/, FinMeta *__restrict__ meta)
+    const T *__restrict__ q, const T *__restrict__ gal, int64_t N, int tile_rows,
+    const int32_t *__restrict__ sel_tiles, double *__restrict__ cand /*[Q][KS_MAX*32]*/, FinMeta *__restrict__ meta)
 {
     constexpr int E = PER * 64;
     const int slot = blockIdx.x, qi = blockIdx.y;
@@ -504,16 +615,17 @@ __global__ __launch_bounds__(FIN_THREADS) void rescore_kernel(
     qq.load(q + (size_t)qi * E, m);
     QuadRow<T, PER> gr[2];
     bool live[2];
+    const int passes = tile_rows / 16;      // 2 for 32-row (bf16) tiles, 1 for 16-row (fp32) tiles
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const int64_t row = (int64_t)tile * TILE_ROWS + u * 16 + grp;
-        live[u] = tile != KEY_NONE && row < N;
+        const int64_t row = (int64_t)tile * tile_rows + u * 16 + grp;
+        live[u] = u < passes && tile != KEY_NONE && row < N;
         gr[u].load(gal + (size_t)(live[u] ? row : 0) * E, m);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const double s = quad_dot<T, PER>(qq, gr[u]);
-        if (m == 0) cand[((size_t)qi * KS_MAX + slot) * TILE_ROWS + u * 16 + grp] = live[u] ? s : -INFINITY;
+        if (m == 0 && u < passes) cand[((size_t)qi * KS_MAX + slot) * TILE_ROWS + u * 16 + grp] = live[u] ? s : -INFINITY;
     }
     if (slot == 0 && grp == 0) {   // ||q||: sizes the certificate's margin
         double qn2 = 0.0;
@@ -526,7 +638,7 @@ __global__ __launch_bounds__(FIN_THREADS) void rescore_kernel(
 }
 
 __global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
-    int64_t N, int k, int ks, const int32_t *__restrict__ sel_tiles, const double *__restrict__ cand,
+    int64_t N, int k, int ks, int tile_rows, const int32_t *__restrict__ sel_tiles, const double *__restrict__ cand,
     const FinMeta *__restrict__ meta, float scale, float eps_coef, int32_t *__restrict__ idx,
     float *__restrict__ score, double *__restrict__ dot64, int32_t *__restrict__ status,
     int32_t *__restrict__ need_exact)
@@ -537,12 +649,14 @@ __global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
     const int qi = blockIdx.x, tid = threadIdx.x;
     const int32_t *st = sel_tiles + (size_t)qi * KS_MAX;
     const double *cs = cand + (size_t)qi * KS_MAX * TILE_ROWS;
-    wg_select<double>(ks * TILE_ROWS, k, [&](int i, double &v, int32_t &key) {
-        const int32_t tile = st[i / TILE_ROWS];
+    // candidate i = (slot i / tile_rows, row-in-tile i % tile_rows); cand keeps a 32-entry stride per slot
+    wg_select<double>(ks * tile_rows, k, [&](int i, double &v, int32_t &key) {
+        const int slot = i / tile_rows, rr = i % tile_rows;
+        const int32_t tile = st[slot];
         if (tile == KEY_NONE) return false;
-        const int64_t row = (int64_t)tile * TILE_ROWS + (i % TILE_ROWS);
+        const int64_t row = (int64_t)tile * tile_rows + rr;
         if (row >= N) return false;
-        key = (int32_t)row; v = cs[i]; return true; }, out_v, out_k, &scd);
+        key = (int32_t)row; v = cs[slot * TILE_ROWS + rr]; return true; }, out_v, out_k, &scd);
     if (tid < k) {
         const size_t o = (size_t)qi * k + tid;
         const bool has = out_k[tid] != KEY_NONE;
@@ -805,20 +919,22 @@ __global__ __launch_bounds__(64) void merge_kernel(const int64_t *__restrict__ i
 // host side
 // ---------------------------------------------------------------------------------------------
 struct SearchPlan {
-    int ntiles, tpt, ntasks, nslab, ks;
+    int ntiles, tpt, ntasks, nslab, ks, tile_rows, qmax;
     int64_t rows_per_slab;
     bool fast;  // MFMA scan usable
     size_t off_bmax, off_tmax, off_flags, off_partial, off_seltiles, off_cand, off_meta, total;
 };
 
 static bool scan_supports_E(int E) { return E == 128 || E == 256 || E == 512 || E == 768; }
-static int scan_qmax(int E) { return E <= 512 ? 256 : 128; }
+static int scan_qmax(int E, mmr_dtype dt) { return (E <= 512 ? 256 : 128) / (dt == MMR_F32 ? 2 : 1); }
 static bool exact_supports_E(int E) { return E == 128 || E == 256 || E == 512 || E == 768 || E == 1024; }
 
 static SearchPlan make_plan(int64_t N, int E, int Q, int k, mmr_dtype dt)
 {
     SearchPlan p{};
-    p.ntiles = (int)((N + TILE_ROWS - 1) / TILE_ROWS);
+    p.tile_rows = dt == MMR_F32 ? TILE_ROWS_F32 : TILE_ROWS;
+    p.qmax = scan_qmax(E, dt);
+    p.ntiles = (int)((N + p.tile_rows - 1) / p.tile_rows);
     if (p.ntiles <= 256) p.tpt = 1;
     else {
         const int m = (p.ntiles + 256 * MAX_TPT - 1) / (256 * MAX_TPT);
@@ -830,11 +946,11 @@ static SearchPlan make_plan(int64_t N, int E, int Q, int k, mmr_dtype dt)
     if (force_tpt >= 1 && force_tpt <= MAX_TPT) p.tpt = force_tpt;
     p.ntasks = (p.ntiles + p.tpt - 1) / p.tpt;
     p.ks = k + 6 > KS_MAX ? KS_MAX : k + 6;
-    p.fast = dt == MMR_BF16 && scan_supports_E(E) && k + 6 <= KS_MAX && N > 0;
+    p.fast = scan_supports_E(E) && k + 6 <= KS_MAX && N > 0;
     int nslab = (int)((N + 2047) / 2048);
     p.nslab = nslab < 1 ? 1 : (nslab > 64 ? 64 : nslab);
     p.rows_per_slab = (N + p.nslab - 1) / p.nslab;
-    const int qc = Q < scan_qmax(E) ? (Q + 31) / 32 * 32 : scan_qmax(E);
+    const int qc = Q < p.qmax ? (Q + 31) / 32 * 32 : p.qmax;
     size_t off = 0;
     p.off_bmax = off; off += align_up((size_t)p.ntiles * qc * sizeof(float), 256);
     p.off_tmax = off; off += align_up((size_t)p.ntasks * qc * sizeof(float), 256);
@@ -867,6 +983,25 @@ static int launch_scan(const bf16_t *q, const bf16_t *gal, int Qc, int64_t N, co
     return MMR_OK;
 }
 
+template <int E>
+static int launch_scan_f32(const float *q, const float *gal, int Qc, int64_t N, const SearchPlan &p, int qpad,
+                           float *bmax, float *tmax, hipStream_t st)
+{
+    ProfScope prof(MMR_PROF_SCAN, st);
+    using C = ScanF32Cfg<E>;
+    const int lds = SCAN_NBUF * C::TILE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_f32_kernel<E>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(scan_f32_kernel<E>, dim3(p.ntasks), dim3(C::SCAN_THREADS), lds, st, q, gal, Qc, N, p.ntiles, p.tpt,
+                       qpad / 16, qpad, bmax, tmax);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
 template <typename T, int PER>
 static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, const SearchPlan &p, int qpad,
                            const float *bmax, const float *tmax, float scale, float eps_coef, int32_t *idx,
@@ -877,9 +1012,11 @@ static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, c
     hipLaunchKernelGGL(select_kernel, dim3(Qc), dim3(FIN_THREADS), 0, st, p.ks, p.ntiles, p.tpt, p.ntasks, qpad, bmax,
                        tmax, sel_tiles, meta);
     MMR_CHECK_LAUNCH();
-    hipLaunchKernelGGL((rescore_kernel<T, PER>), dim3(p.ks, Qc), dim3(FIN_THREADS), 0, st, q, gal, N, sel_tiles, cand, meta);
+    hipLaunchKernelGGL((rescore_kernel<T, PER>), dim3(p.ks, Qc), dim3(FIN_THREADS), 0, st, q, gal, N, p.tile_rows, sel_tiles,
+                       cand, meta);
     MMR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(rank_kernel, dim3(Qc), dim3(FIN_THREADS), 0, st, N, k, p.ks, sel_tiles, cand, meta, scale, eps_coef,
+    hipLaunchKernelGGL(rank_kernel, dim3(Qc), dim3(FIN_THREADS), 0, st, N, k, p.ks, p.tile_rows, sel_tiles, cand, meta, scale,
+                       eps_coef,
                        idx, score, dot64, status, flags);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
@@ -917,7 +1054,8 @@ using namespace mmr;
 extern "C" size_t mmr_search_workspace_bytes(int64_t N, int E, int Q, int k)
 {
     if (N < 0 || Q < 0 || k < 1) return 0;
-    return make_plan(N, E, Q, k, MMR_BF16).total;
+    const size_t a = make_plan(N, E, Q, k, MMR_BF16).total, b = make_plan(N, E, Q, k, MMR_F32).total;
+    return a > b ? a : b;
 }
 
 extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
@@ -953,37 +1091,65 @@ extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dty
     }
 
     if (p.fast) {
-        // fp32 MFMA accumulation error of a length-E bf16 dot is <= ~E*2^-24*|q||g|; the margin below
-        // is that worst case for E<=1024 with 25% headroom.  It gates the fast path only.
+        // fp32 MFMA accumulation error of a length-E dot is <= ~E*2^-24*|q||g| (bf16 x bf16 products are exact
+        // in fp32; fp32 x fp32 products add one rounding each, same order); the margin below is that worst case
+        // for E<=1024 with headroom.  It gates the fast path only.
         const float eps_coef = 8e-5f * gallery_norm_bound;
-        const int qmax = scan_qmax(E);
+        const int qmax = p.qmax;
         for (int q0 = 0; q0 < Q; q0 += qmax) {
             const int Qc = (Q - q0) < qmax ? (Q - q0) : qmax;
             const int qpad = (Qc + 31) / 32 * 32;
-            const bf16_t *qc = (const bf16_t *)q + (size_t)q0 * E;
+            const char *qc = (const char *)q + (size_t)q0 * E * esz;
             int rc;
-            switch (E) {
-                case 128: rc = launch_scan<128>(qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                case 256: rc = launch_scan<256>(qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                case 512: rc = launch_scan<512>(qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                default: rc = launch_scan<768>(qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+            if (dtype == MMR_BF16) {
+                switch (E) {
+                    case 128: rc = launch_scan<128>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    case 256: rc = launch_scan<256>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    case 512: rc = launch_scan<512>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    default: rc = launch_scan<768>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                }
+            } else {
+                switch (E) {
+                    case 128: rc = launch_scan_f32<128>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    case 256: rc = launch_scan_f32<256>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    case 512: rc = launch_scan_f32<512>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    default: rc = launch_scan_f32<768>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                }
             }
             if (rc != MMR_OK) return rc;
-            MMR_DISPATCH_PER(E, bf16_t, {
-                rc = launch_finalize<bf16_t, PER>(qc, (const bf16_t *)gallery, Qc, N, k, p, qpad, bmax, tmax, scale,
-                                                  eps_coef, idx + (size_t)q0 * k, score + (size_t)q0 * k,
-                                                  dot64 ? dot64 + (size_t)q0 * k : nullptr,
-                                                  status ? status + q0 : nullptr, flags + q0,
-                                                  (int32_t *)(ws + p.off_seltiles), (double *)(ws + p.off_cand),
-                                                  (FinMeta *)(ws + p.off_meta), st);
-            });
+            int32_t *o_idx = idx + (size_t)q0 * k;
+            float *o_score = score + (size_t)q0 * k;
+            double *o_dot = dot64 ? dot64 + (size_t)q0 * k : nullptr;
+            int32_t *o_status = status ? status + q0 : nullptr;
+            if (dtype == MMR_BF16) {
+                MMR_DISPATCH_PER(E, bf16_t, {
+                    rc = launch_finalize<bf16_t, PER>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, k, p, qpad, bmax,
+                                                      tmax, scale, eps_coef, o_idx, o_score, o_dot, o_status, flags + q0,
+                                                      (int32_t *)(ws + p.off_seltiles), (double *)(ws + p.off_cand),
+                                                      (FinMeta *)(ws + p.off_meta), st);
+                });
+            } else {
+                MMR_DISPATCH_PER(E, float, {
+                    rc = launch_finalize<float, PER>((const float *)qc, (const float *)gallery, Qc, N, k, p, qpad, bmax, tmax,
+                                                     scale, eps_coef, o_idx, o_score, o_dot, o_status, flags + q0,
+                                                     (int32_t *)(ws + p.off_seltiles), (double *)(ws + p.off_cand),
+                                                     (FinMeta *)(ws + p.off_meta), st);
+                });
+            }
             if (rc != MMR_OK) return rc;
         }
         int rc;
-        MMR_DISPATCH_PER(E, bf16_t, {
-            rc = launch_exh<bf16_t, PER>((const bf16_t *)q, (const bf16_t *)gallery, Q, N, k, p, scale, flags, partial,
-                                         idx, score, dot64, st);
-        });
+        if (dtype == MMR_BF16) {
+            MMR_DISPATCH_PER(E, bf16_t, {
+                rc = launch_exh<bf16_t, PER>((const bf16_t *)q, (const bf16_t *)gallery, Q, N, k, p, scale, flags, partial,
+                                             idx, score, dot64, st);
+            });
+        } else {
+            MMR_DISPATCH_PER(E, float, {
+                rc = launch_exh<float, PER>((const float *)q, (const float *)gallery, Q, N, k, p, scale, flags, partial,
+                                            idx, score, dot64, st);
+            });
+        }
         return rc;
     }
 

@@ -41,10 +41,7 @@ def test_topk_matches_golden(S, device, golden_dir, N, Q, tag):
     assert np.array_equal(idx.cpu().numpy().astype(np.int32), g[key + "_idx"])       # bit-exact ranks
     assert np.array_equal(d64.cpu().numpy(), g[key + "_dot64"])                      # same fp64 order
     assert np.array_equal(vals.cpu().numpy(), g[key + "_score"])
-    if tag == "bf16":
-        assert int(status.sum()) == 0, "tie-free fixture should certify on the MFMA fast path"
-    else:
-        assert int(status.sum()) == Q
+    assert int(status.sum()) == 0, "tie-free fixture should certify on the MFMA fast path (bf16 and fp32 scans)"
 
 
 def test_tie_rule_lowest_index_first(S, device, golden_dir):
@@ -112,6 +109,23 @@ def test_uncertified_queries_fall_back_to_exact(S, oracle, device):
     assert np.array_equal(d64.cpu().numpy(), od)
     assert int(status[0]) == 1          # crowded boundary -> exact path
     assert int(status[1]) == 0          # ordinary query -> fast path
+
+
+def test_fp32_gallery_fast_path_and_fallback(S, oracle, device):
+    """fp32 galleries (the dtype of the reference's feature caches) take the fp32-MFMA scan; crowded boundaries
+    still fall back to the exhaustive path and stay exact."""
+    gal = synth.synth_unit_rows(70001, 512, seed=51)
+    q = synth.synth_unit_rows(130, 512, seed=52)              # > 128 queries: two scan passes
+    dup = list(range(1000, 41000, 1000))                      # 40 exact duplicates spread over 40 different tiles
+    gal[dup] = gal[123].clone()
+    q[0] = gal[123].clone()
+    vals, idx, d64, status = S.cosine_topk(q.to(device), gal.to(device), 10, scale=100.0, return_dot64=True,
+                                           return_status=True)
+    oi, os_, od = oracle.cosine_topk(q, gal, 10, scale=100.0)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d64.cpu().numpy(), od)
+    assert np.array_equal(vals.cpu().numpy(), os_)
+    assert idx[0].tolist() == [123] + dup[:9]                  # ties -> lowest row ids
+    assert int(status[0]) == 1 and int(status[1:].sum()) == 0   # more tied tiles than KS: the only fallback
 
 
 def test_similarity_and_l2norm(S, oracle, device):
