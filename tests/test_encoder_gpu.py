@@ -291,3 +291,33 @@ def test_encode_gallery_and_cache(device, tmp_path):
     kk, vv = gallery.build_cache_model(model, lambda: batches, augment_epoch=2, num_classes=3)
     assert kk.shape == (model.cfg.embed_dim, 21) and vv.shape == (21, 3)
     assert torch.allclose(kk.norm(dim=0), torch.ones(21, device=device), atol=1e-4)
+
+
+def test_baseline_config0_and_config2_end_to_end(device):
+    """BASELINE configs[0] shape (ViT-B/32 encode of 128 synthetic images -> L2-norm -> top-10 over a 10k x 512 fp32
+    gallery, seeds 0 / 1) and configs[2] shape (text tower -> search): the ranking computed on the device features
+    is bit-exact against the oracle ranking of those same features, and the features match the fp32 oracle."""
+    from oracle import clip_ref, search_ref
+    model, _ = mmr_amd.load("ViT-B/32", device=device)
+    px = synth.synth_images(128, 224, seed=0)
+    feats = model.encode_image(px.to(device))                       # fp32 outputs, like the reference on CPU
+    feats /= feats.norm(dim=-1, keepdim=True)                       # the reference's in-place normalise
+    gal = synth.synth_unit_rows(10_000, 512, seed=1)
+    vals, idx, d64 = mmr_amd.cosine_topk(feats, gal.to(device), 10, scale=100.0, return_dot64=True)
+    oi, os_, od = search_ref.cosine_topk(feats.cpu(), gal, 10, scale=100.0)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d64.cpu().numpy(), od)
+    assert np.abs(vals.cpu().numpy() - os_).max() <= 1e-5
+    w = weights.make_clip_weights(model.cfg)
+    with torch.no_grad():
+        ref = clip_ref.l2_normalize(clip_ref.encode_image(w, model.cfg.vision, px[:3].bfloat16().float()))
+    assert _cos(feats[:3].cpu(), ref).min().item() >= 1 - 1e-3
+    # cosine scores of the device features vs the oracle features against the same gallery: within 1e-3
+    assert (feats[:3].cpu() @ gal.t() - ref @ gal.t()).abs().max().item() <= 1e-3
+    # configs[2]: text -> image search over a bf16 gallery built from encoded images
+    model.bfloat16()
+    gallery = model.encode_image(px.to(device), normalize=True)     # [128,512] bf16
+    ids = synth.synth_token_ids(9, 77, model.cfg.text.vocab, seed=5)
+    tq = model.encode_text(ids.to(device), normalize=True)
+    v2, i2, d2 = mmr_amd.cosine_topk(tq, gallery, 10, return_dot64=True)
+    oi2, _, od2 = search_ref.cosine_topk(tq.cpu(), gallery.cpu(), 10)
+    assert np.array_equal(i2.cpu().numpy(), oi2) and np.array_equal(d2.cpu().numpy(), od2)
