@@ -431,27 +431,101 @@ struct SelScratch {
     int32_t bk;
 };
 
+// ---- branch-free candidate keys.  A candidate (value, key) becomes an unsigned sort key whose MAXIMUM is the
+// best candidate in (-value, +key) order: high part = order-preserving bits of the value, low part = ~key.
+// Empty slots are all-zero (below every real candidate: real low parts are >= 1 because key < KEY_NONE).
+__device__ __forceinline__ uint32_t ord_f32(float v) {
+    const uint32_t b = __float_as_uint(v);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(uint32_t o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
+}
+__device__ __forceinline__ uint64_t ord_f64(double v) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double unord_f64(uint64_t o) {
+    return __longlong_as_double((long long)((o >> 63) ? (o & 0x7fffffffffffffffull) : ~o));
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+// DPP controls: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror, row_mirror: four steps that leave the
+// maximum of each 16-lane row in all of its lanes (plain VALU, no LDS round trip); rows are then merged
+// with two cross-row shuffles.
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
+
+struct Key64 {    // float value
+    uint64_t k;
+    __device__ __forceinline__ static Key64 make(float v, int32_t key) { return {((uint64_t)ord_f32(v) << 32) | (uint32_t)~(uint32_t)key}; }
+    __device__ __forceinline__ static Key64 none() { return {0}; }
+    __device__ __forceinline__ bool empty() const { return k == 0; }
+    __device__ __forceinline__ void take_max(const Key64 &o) { k = o.k > k ? o.k : k; }
+    __device__ __forceinline__ bool same(const Key64 &o) const { return k == o.k; }
+    template <int CTRL> __device__ __forceinline__ Key64 via_dpp() const {
+        return {((uint64_t)dpp<CTRL>((uint32_t)(k >> 32)) << 32) | dpp<CTRL>((uint32_t)k)};
+    }
+    __device__ __forceinline__ Key64 via_xor(int off) const { return {(uint64_t)__shfl_xor((unsigned long long)k, off, 64)}; }
+    __device__ __forceinline__ float value() const { return unord_f32((uint32_t)(k >> 32)); }
+    __device__ __forceinline__ int32_t key() const { return (int32_t)~(uint32_t)k; }
+};
+struct Key96 {    // double value
+    uint64_t hi; uint32_t lo;
+    __device__ __forceinline__ static Key96 make(double v, int32_t key) { return {ord_f64(v), (uint32_t)~(uint32_t)key}; }
+    __device__ __forceinline__ static Key96 none() { return {0, 0}; }
+    __device__ __forceinline__ bool empty() const { return (hi | lo) == 0; }
+    __device__ __forceinline__ void take_max(const Key96 &o) {
+        const bool t = (o.hi > hi) | ((o.hi == hi) & (o.lo > lo));
+        hi = t ? o.hi : hi; lo = t ? o.lo : lo;
+    }
+    __device__ __forceinline__ bool same(const Key96 &o) const { return (hi == o.hi) & (lo == o.lo); }
+    template <int CTRL> __device__ __forceinline__ Key96 via_dpp() const {
+        return {((uint64_t)dpp<CTRL>((uint32_t)(hi >> 32)) << 32) | dpp<CTRL>((uint32_t)hi), dpp<CTRL>(lo)};
+    }
+    __device__ __forceinline__ Key96 via_xor(int off) const {
+        return {(uint64_t)__shfl_xor((unsigned long long)hi, off, 64), (uint32_t)__shfl_xor((int)lo, off, 64)};
+    }
+    __device__ __forceinline__ double value() const { return unord_f64(hi); }
+    __device__ __forceinline__ int32_t key() const { return (int32_t)~lo; }
+};
+template <typename V> struct KeyOf;
+template <> struct KeyOf<float> { using type = Key64; };
+template <> struct KeyOf<double> { using type = Key96; };
+
+template <typename KT>
+__device__ __forceinline__ KT wave_max_key(KT b) {
+    b.take_max(b.template via_dpp<DPP_XOR1>());
+    b.take_max(b.template via_dpp<DPP_XOR2>());
+    b.take_max(b.template via_dpp<DPP_HALF_MIRROR>());
+    b.take_max(b.template via_dpp<DPP_MIRROR>());
+    b.take_max(b.via_xor(16));
+    b.take_max(b.via_xor(32));
+    return b;
+}
+
 // `rounds` extractions from the R register candidates of each lane of ONE wave; lane 0 records
 // them.  Exhausted slots come out as (-inf, KEY_NONE).
 template <typename V, int R>
 __device__ __forceinline__ void wave_rounds(V (&v)[R], int32_t (&key)[R], int rounds, V *out_v, int32_t *out_k,
                                             int lane) {
+    using KT = typename KeyOf<V>::type;
+    KT c[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) c[j] = key[j] == KEY_NONE ? KT::none() : KT::make(v[j], key[j]);
     for (int r = 0; r < rounds; ++r) {
-        V bv = v[0];
-        int32_t bk = key[0];
+        KT b = c[0];
 #pragma unroll
-        for (int j = 1; j < R; ++j)
-            if (before(v[j], key[j], bv, bk)) { bv = v[j]; bk = key[j]; }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const V ov = __shfl_xor(bv, off, 64);
-            const int32_t ok = __shfl_xor(bk, off, 64);
-            if (before(ov, ok, bv, bk)) { bv = ov; bk = ok; }
+        for (int j = 1; j < R; ++j) b.take_max(c[j]);
+        b = wave_max_key(b);
+        if (lane == 0) {
+            out_v[r] = b.empty() ? (V)-INFINITY : b.value();
+            out_k[r] = b.empty() ? KEY_NONE : b.key();
         }
-        if (lane == 0) { out_v[r] = bv; out_k[r] = bk; }
 #pragma unroll
-        for (int j = 0; j < R; ++j)
-            if (key[j] == bk) { v[j] = (V)-INFINITY; key[j] = KEY_NONE; }
+        for (int j = 0; j < R; ++j) c[j] = c[j].same(b) ? KT::none() : c[j];
     }
 }
 
@@ -947,8 +1021,11 @@ static SearchPlan make_plan(int64_t N, int E, int Q, int k, mmr_dtype dt)
     p.ntasks = (p.ntiles + p.tpt - 1) / p.tpt;
     p.ks = k + 6 > KS_MAX ? KS_MAX : k + 6;
     p.fast = scan_supports_E(E) && k + 6 <= KS_MAX && N > 0;
+    // exhaustive path: 64 row slabs per query when it is THE path; 16 when it only backs up the fast path
+    // (it is launched unconditionally there and unflagged queries exit at once: fewer idle workgroups)
     int nslab = (int)((N + 2047) / 2048);
-    p.nslab = nslab < 1 ? 1 : (nslab > 64 ? 64 : nslab);
+    const int slab_cap = p.fast ? 16 : 64;
+    p.nslab = nslab < 1 ? 1 : (nslab > slab_cap ? slab_cap : nslab);
     p.rows_per_slab = (N + p.nslab - 1) / p.nslab;
     const int qc = Q < p.qmax ? (Q + 31) / 32 * 32 : p.qmax;
     size_t off = 0;
