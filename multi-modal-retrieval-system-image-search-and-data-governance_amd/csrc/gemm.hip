@@ -141,31 +141,61 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
         return;
     }
 #endif
-    // ---- epilogue: lane holds C[m = .. + fr][n = .. + 4*fg + {0,1,2,3}]
+    // ---- epilogue: in the accumulator layout a lane owns 4 consecutive columns of 16 different rows.  Each
+    // wave transposes its 64x64 sub-tile through a private LDS region (the staging buffers are idle after
+    // the loop's last __syncthreads) and stores whole 128 B (bf16) / 256 B (fp32) row segments.
+    const size_t row_base = (size_t)(m0 + wm * 64);
+    const int col_base = n0 + wn * 64;
+    if constexpr (epi_bf16(EPI)) {
+        char *my = smem + wave * 8192;           // [64 rows][8 chunks of 8 bf16], chunk ^ (row & 7)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + fg * 4;
-        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if constexpr (epi_bias(EPI)) b4 = *reinterpret_cast<const float4 *>(bias + n);
+        for (int ni = 0; ni < 4; ++ni) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
+            const int c = ni * 2 + (fg >> 1);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + wm * 64 + mi * 16 + fr;
-            const float v0 = epi_act<EPI>(acc[ni][mi][0] + b4.x), v1 = epi_act<EPI>(acc[ni][mi][1] + b4.y);
-            const float v2 = epi_act<EPI>(acc[ni][mi][2] + b4.z), v3 = epi_act<EPI>(acc[ni][mi][3] + b4.w);
-            const size_t o = (size_t)m * N + n;
-            if constexpr (epi_bf16(EPI)) {
+            for (int mi = 0; mi < 4; ++mi) {
+                const float v0 = epi_act<EPI>(acc[ni][mi][0] + b4.x), v1 = epi_act<EPI>(acc[ni][mi][1] + b4.y);
+                const float v2 = epi_act<EPI>(acc[ni][mi][2] + b4.z), v3 = epi_act<EPI>(acc[ni][mi][3] + b4.w);
+                const int row = mi * 16 + fr;
                 uint2 pk;
                 pk.x = pack_bf16x2(v0, v1);
                 pk.y = pack_bf16x2(v2, v3);
-                *reinterpret_cast<uint2 *>((bf16_t *)out + o) = pk;
-            } else if constexpr (EPI == EPI_BIAS_RESID_F32) {
-                float4 *p = reinterpret_cast<float4 *>((float *)out + o);
-                float4 h = *p;
-                h.x += v0; h.y += v1; h.z += v2; h.w += v3;
-                *p = h;
-            } else {
-                *reinterpret_cast<float4 *>((float *)out + o) = make_float4(v0, v1, v2, v3);
+                *reinterpret_cast<uint2 *>(my + row * 128 + ((c ^ (row & 7)) << 4) + (fg & 1) * 8) = pk;
             }
+        }
+        const int rc = lane & 7, rr0 = lane >> 3;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = i * 8 + rr0;
+            const uint4 v = *reinterpret_cast<const uint4 *>(my + row * 128 + ((rc ^ (row & 7)) << 4));
+            *reinterpret_cast<uint4 *>((bf16_t *)out + (row_base + row) * N + col_base + rc * 8) = v;
+        }
+    } else {
+        char *my = smem + wave * 16384;          // [64 rows][16 chunks of 4 floats], chunk ^ (row & 15)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (epi_bias(EPI)) b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
+            const int c = ni * 4 + fg;
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const f32x4 a = acc[ni][mi];
+                const int row = mi * 16 + fr;
+                *reinterpret_cast<float4 *>(my + row * 256 + ((c ^ (row & 15)) << 4)) =
+                    make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+            }
+        }
+        const int rc = lane & 15, rr0 = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int row = i * 4 + rr0;
+            float4 v = *reinterpret_cast<const float4 *>(my + row * 256 + ((rc ^ (row & 15)) << 4));
+            float4 *dst = reinterpret_cast<float4 *>((float *)out + (row_base + row) * N + col_base + rc * 4);
+            if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                const float4 h = *dst;
+                v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+            }
+            *dst = v;
         }
     }
 }
