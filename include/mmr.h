@@ -95,6 +95,13 @@ typedef struct {
     int patch;       /* vision only */
     int vocab;       /* text only */
     float ln_eps;
+    int fold_ln;     /* kinds 0/1: 1 = the per-block LayerNorms are folded into the GEMMs that consume them.
+                      * The blob then carries, per layer, QKV_W = bf16(W_qkv * ln1.w[None,:]),
+                      * QKV_B = W_qkv @ ln1.b + b_qkv, QKV_C[n] = sum_k float(QKV_W[n,k]) and the same for
+                      * FC1_{W,B,C} with ln2; LN1_x / LN2_x are not read.  The GEMM epilogue applies
+                      * rstd*(acc - mean*C) + B from row statistics of the fp32 residual stream
+                      * (same arithmetic as LN-then-GEMM up to bf16 rounding of W*gamma instead of LN(h)).
+                      * 0 = separate LayerNorm launches, original tensors.  Must be 0 for kind 2. */
 } mmr_tower_cfg;
 
 /* Tensors of the weight blob.  Matrices are bf16 row-major [out,in]; vectors/embeddings fp32
@@ -110,6 +117,9 @@ typedef enum {
     MMR_P_POOL_W,   /* bf16 [d,d] pooler dense */
     MMR_P_POOL_B,   /* fp32 [d] */
     MMR_P_PROJ_B,   /* fp32 [E] classifier bias (MMR_P_PROJ is the classifier weight [E,d]) */
+    /* fold_ln towers only, per layer: */
+    MMR_P_QKV_C,    /* fp32 [3d] row sums of the gamma-folded QKV weight */
+    MMR_P_FC1_C,    /* fp32 [mlp] row sums of the gamma-folded FC1 weight */
     MMR_P_COUNT
 } mmr_param;
 

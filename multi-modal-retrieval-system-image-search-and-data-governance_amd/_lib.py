@@ -25,12 +25,13 @@ class TowerCfg(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in
                 ("kind", "width", "layers", "heads", "mlp", "tokens", "embed_dim", "image_size", "patch", "vocab")]
     _fields_.append(("ln_eps", ctypes.c_float))
+    _fields_.append(("fold_ln", ctypes.c_int))
 
 
 # parameter ids, mirrored from include/mmr.h (mmr_param)
 (P_PATCH_W, P_CLS, P_POS, P_LN_PRE_W, P_LN_PRE_B, P_LN1_W, P_LN1_B, P_QKV_W, P_QKV_B, P_OUT_W, P_OUT_B,
  P_LN2_W, P_LN2_B, P_FC1_W, P_FC1_B, P_FC2_W, P_FC2_B, P_LN_FINAL_W, P_LN_FINAL_B, P_PROJ, P_TOK_EMB,
- P_TYPE_EMB, P_POOL_W, P_POOL_B, P_PROJ_B, P_COUNT) = range(26)
+ P_TYPE_EMB, P_POOL_W, P_POOL_B, P_PROJ_B, P_QKV_C, P_FC1_C, P_COUNT) = range(28)
 
 _lib = None
 

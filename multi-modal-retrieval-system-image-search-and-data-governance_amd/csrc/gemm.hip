@@ -24,15 +24,22 @@ constexpr int TILE_B_BYTES = BN * BK * 2;
 constexpr int STAGE_BYTES = TILE_A_BYTES + TILE_B_BYTES;
 
 enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_STORE_F32 = 3,
-       EPI_BIAS_F32 = 4, EPI_BIAS_GELU_ERF_BF16 = 5, EPI_BIAS_TANH_BF16 = 6, EPI_COUNT = 7 };
+       EPI_BIAS_F32 = 4, EPI_BIAS_GELU_ERF_BF16 = 5, EPI_BIAS_TANH_BF16 = 6,
+       // LayerNorm folded into the GEMM that consumes it (A = bf16 of the UN-normalised residual, W' = W*gamma):
+       //   LN(h) . W^T + b  =  rstd * (h . W'^T - mean * colsum(W')) + (beta . W^T + b)
+       EPI_LNFOLD_BF16 = 7, EPI_LNFOLD_GELU_BF16 = 8,
+       // residual update that also emits what the NEXT folded GEMM needs: bf16(h_new) and per-row (sum, sumsq)
+       EPI_RESID_STATS_F32 = 9, EPI_COUNT = 10 };
 
-constexpr bool epi_bf16(int e) { return e == EPI_BIAS_BF16 || e == EPI_BIAS_GELU_BF16 || e == EPI_BIAS_GELU_ERF_BF16 || e == EPI_BIAS_TANH_BF16; }
+constexpr bool epi_lnfold(int e) { return e == EPI_LNFOLD_BF16 || e == EPI_LNFOLD_GELU_BF16; }
+constexpr bool epi_bf16(int e) { return e == EPI_BIAS_BF16 || e == EPI_BIAS_GELU_BF16 || e == EPI_BIAS_GELU_ERF_BF16 || e == EPI_BIAS_TANH_BF16 || epi_lnfold(e); }
 constexpr bool epi_bias(int e) { return e != EPI_STORE_F32; }
+constexpr bool epi_resid(int e) { return e == EPI_BIAS_RESID_F32 || e == EPI_RESID_STATS_F32; }
 
 // activation fused into the bf16 epilogues
 template <int EPI>
 __device__ __forceinline__ float epi_act(float v) {
-    if constexpr (EPI == EPI_BIAS_GELU_BF16) {
+    if constexpr (EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_LNFOLD_GELU_BF16) {
         // QuickGELU x * sigmoid(1.702 x) (transformers/activations.py:117-123); hardware exp/rcp (1 ulp)
         // is far inside bf16 rounding.  Same formulation in both tile sizes.
         return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
@@ -62,7 +69,7 @@ template <int EPI>
 #endif
 __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
-    const float *__restrict__ bias, void *__restrict__ out)
+    const float *__restrict__ bias, void *__restrict__ out, GemmAux aux)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -105,7 +112,15 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
 
     const int fr = lane & 15, fg = lane >> 4;
     const int nkt = K / BK;
-    stage(0, 0);
+    float2 *row_stats = reinterpret_cast<float2 *>(smem + 2 * STAGE_BYTES);   // LNFOLD only: (mean, rstd) of the BM tile rows
+    if constexpr (epi_lnfold(EPI)) {
+        LnfoldLoads ld;
+        lnfold_issue(aux, m0, ld);
+        stage(0, 0);
+        lnfold_finish(aux, ld, row_stats);
+    } else {
+        stage(0, 0);
+    }
     __syncthreads();
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -154,14 +169,29 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
     const int col_base = n0 + wn * 64;
     if constexpr (epi_bf16(EPI)) {
         char *my = smem + wave * 8192;           // [64 rows][8 chunks of 8 bf16], chunk ^ (row & 7)
+        float mean[4], rstd[4];
+        if constexpr (epi_lnfold(EPI)) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const float2 st = row_stats[wm * 64 + mi * 16 + fr];
+                mean[mi] = st.x; rstd[mi] = st.y;
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const float4 b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (epi_lnfold(EPI)) c4 = *reinterpret_cast<const float4 *>(aux.colsum + col_base + ni * 16 + fg * 4);
             const int c = ni * 2 + (fg >> 1);
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const float v0 = epi_act<EPI>(acc[ni][mi][0] + b4.x), v1 = epi_act<EPI>(acc[ni][mi][1] + b4.y);
-                const float v2 = epi_act<EPI>(acc[ni][mi][2] + b4.z), v3 = epi_act<EPI>(acc[ni][mi][3] + b4.w);
+                float a0 = acc[ni][mi][0], a1 = acc[ni][mi][1], a2 = acc[ni][mi][2], a3 = acc[ni][mi][3];
+                if constexpr (epi_lnfold(EPI)) {
+                    a0 = rstd[mi] * (a0 - mean[mi] * c4.x); a1 = rstd[mi] * (a1 - mean[mi] * c4.y);
+                    a2 = rstd[mi] * (a2 - mean[mi] * c4.z); a3 = rstd[mi] * (a3 - mean[mi] * c4.w);
+                }
+                const float v0 = epi_act<EPI>(a0 + b4.x), v1 = epi_act<EPI>(a1 + b4.y);
+                const float v2 = epi_act<EPI>(a2 + b4.z), v3 = epi_act<EPI>(a3 + b4.w);
                 const int row = mi * 16 + fr;
                 uint2 pk;
                 pk.x = pack_bf16x2(v0, v1);
@@ -196,12 +226,22 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
         for (int i = 0; i < 16; ++i) {
             const int row = i * 4 + rr0;
             float4 v = *reinterpret_cast<const float4 *>(my + row * 256 + ((rc ^ (row & 15)) << 4));
-            float4 *dst = reinterpret_cast<float4 *>((float *)out + (row_base + row) * N + col_base + rc * 4);
-            if constexpr (EPI == EPI_BIAS_RESID_F32) {
+            const size_t grow = row_base + row;
+            float4 *dst = reinterpret_cast<float4 *>((float *)out + grow * N + col_base + rc * 4);
+            if constexpr (epi_resid(EPI)) {
                 const float4 h = *dst;
                 v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
             }
             *dst = v;
+            if constexpr (EPI == EPI_RESID_STATS_F32) {
+                uint2 pk;
+                pk.x = pack_bf16x2(v.x, v.y);
+                pk.y = pack_bf16x2(v.z, v.w);
+                *reinterpret_cast<uint2 *>(aux.xout + grow * N + col_base + rc * 4) = pk;
+                const float s1 = row16_sum((v.x + v.y) + (v.z + v.w));
+                const float s2 = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+                if (rc == 0) aux.stats_out[grow * (N >> 6) + (col_base >> 6)] = make_float2(s1, s2);
+            }
         }
     }
 }
@@ -235,7 +275,7 @@ constexpr int GEMM2_LDS = 2 * STAGE2_BYTES;         // 128 KiB
 template <int EPI>
 __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
-    const float *__restrict__ bias, void *__restrict__ out)
+    const float *__restrict__ bias, void *__restrict__ out, GemmAux aux)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
@@ -282,8 +322,12 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     const int w_row0 = (wc & 1) * 64;
 
     // prologue: stream elements 0..5 = W0,W1,A0,A1 of tile 0 and W0,W1 of tile 1
+    float2 *row_stats = reinterpret_cast<float2 *>(smem + GEMM2_LDS);   // LNFOLD only: (mean, rstd) of the BM2 tile rows
+    LnfoldLoads ld;
+    if constexpr (epi_lnfold(EPI)) lnfold_issue(aux, m0, ld);
     stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
     if (nkt > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    if constexpr (epi_lnfold(EPI)) lnfold_finish(aux, ld, row_stats);
     __builtin_amdgcn_s_barrier();
     // Stagger: waves 4-7 (wr == 1, the SIMD partners of waves 0-3) run one segment behind, so on every
     // SIMD one wave is in a LOAD segment (ds_read + global_load_lds) while its partner is in a COMPUTE
@@ -411,14 +455,29 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     const int col_base = n0 + wc * 64;
     if constexpr (epi_bf16(EPI)) {
         // image: [128 rows][8 chunks of 8 bf16], chunk index XOR (row & 7)
+        float mean[8], rstd[8];
+        if constexpr (epi_lnfold(EPI)) {
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const float2 st = row_stats[wr * 128 + mi * 16 + fr];
+                mean[mi] = st.x; rstd[mi] = st.y;
+            }
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             const float4 b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (epi_lnfold(EPI)) c4 = *reinterpret_cast<const float4 *>(aux.colsum + col_base + ni * 16 + fg * 4);
             const int c = ni * 2 + (fg >> 1);
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
-                const float v0 = epi_act<EPI>(acc[ni][mi][0] + b4.x), v1 = epi_act<EPI>(acc[ni][mi][1] + b4.y);
-                const float v2 = epi_act<EPI>(acc[ni][mi][2] + b4.z), v3 = epi_act<EPI>(acc[ni][mi][3] + b4.w);
+                float a0 = acc[ni][mi][0], a1 = acc[ni][mi][1], a2 = acc[ni][mi][2], a3 = acc[ni][mi][3];
+                if constexpr (epi_lnfold(EPI)) {
+                    a0 = rstd[mi] * (a0 - mean[mi] * c4.x); a1 = rstd[mi] * (a1 - mean[mi] * c4.y);
+                    a2 = rstd[mi] * (a2 - mean[mi] * c4.z); a3 = rstd[mi] * (a3 - mean[mi] * c4.w);
+                }
+                const float v0 = epi_act<EPI>(a0 + b4.x), v1 = epi_act<EPI>(a1 + b4.y);
+                const float v2 = epi_act<EPI>(a2 + b4.z), v3 = epi_act<EPI>(a3 + b4.w);
                 const int row = mi * 16 + fr;
                 uint2 pk;
                 pk.x = pack_bf16x2(v0, v1);
@@ -455,80 +514,104 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
             for (int i = 0; i < 16; ++i) {
                 const int row = i * 4 + rr0;
                 float4 v = *reinterpret_cast<const float4 *>(my + row * 256 + ((rc ^ (row & 15)) << 4));
-                float4 *dst = reinterpret_cast<float4 *>((float *)out + (row_base + mh * 64 + row) * N + col_base + rc * 4);
-                if constexpr (EPI == EPI_BIAS_RESID_F32) {
+                const size_t grow = row_base + mh * 64 + row;
+                float4 *dst = reinterpret_cast<float4 *>((float *)out + grow * N + col_base + rc * 4);
+                if constexpr (epi_resid(EPI)) {
                     const float4 h = *dst;
                     v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
                 }
                 *dst = v;
+                if constexpr (EPI == EPI_RESID_STATS_F32) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(v.x, v.y);
+                    pk.y = pack_bf16x2(v.z, v.w);
+                    *reinterpret_cast<uint2 *>(aux.xout + grow * N + col_base + rc * 4) = pk;
+                    const float s1 = row16_sum((v.x + v.y) + (v.z + v.w));
+                    const float s2 = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+                    if (rc == 0) aux.stats_out[grow * (N >> 6) + (col_base >> 6)] = make_float2(s1, s2);
+                }
             }
         }
     }
 }
 
 template <int EPI>
-static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st)
+static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
+                          const GemmAux &aux, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<EPI>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS + BM2 * 8));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, dim3((M / BM2) * (N / BN2)), dim3(GEMM2_THREADS), GEMM2_LDS, st, A, W, M, N,
-                       K, bias, out);
+    hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, dim3((M / BM2) * (N / BN2)), dim3(GEMM2_THREADS), GEMM2_LDS + BM2 * 8, st, A, W, M, N,
+                       K, bias, out, aux);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
 
 template <int EPI>
-static int launch_gemm128(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st)
+static int launch_gemm128(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
+                          const GemmAux &aux, hipStream_t st)
 {
-    const int lds = 2 * STAGE_BYTES;
+    const int lds = 2 * STAGE_BYTES + BM * 8;
     static bool attr_set = false;
     if (!attr_set) {
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((M / BM) * (N / BN)), dim3(GEMM_THREADS), lds, st, A, W, M, N, K, bias, out);
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((M / BM) * (N / BN)), dim3(GEMM_THREADS), lds, st, A, W, M, N, K, bias, out,
+                       aux);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
 
 // host launcher (internal): shapes are validated by the caller in tower.hip
-int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
-                hipStream_t st)
+int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
+                    const GemmAux &aux, hipStream_t st)
 {
     if (M % BM || N % BN || K % BK || M <= 0 || N <= 0 || K <= 0) {
         set_error("gemm: M=%d N=%d K=%d must be positive multiples of %d/%d/%d", M, N, K, BM, BN, BK);
         return MMR_EINVAL;
     }
+    if (epi < 0 || epi >= EPI_COUNT) { set_error("gemm: unknown epilogue %d", epi); return MMR_EINVAL; }
+    if (epi_lnfold(epi) && (aux.np != K / 64 || aux.np > LNFOLD_MAX_NP || !aux.stats_in || !aux.colsum)) {
+        set_error("gemm: LN-fold epilogue needs K/64 = %d <= %d row-stat partials, stats and column sums", K / 64, LNFOLD_MAX_NP);
+        return MMR_EINVAL;
+    }
+    if (epi == EPI_RESID_STATS_F32 && (!aux.stats_out || !aux.xout)) { set_error("gemm: RESID_STATS epilogue needs stats_out and xout"); return MMR_EINVAL; }
     ProfScope prof(MMR_PROF_GEMM, st);
     static const int force = getenv("MMR_GEMM_TILE") ? atoi(getenv("MMR_GEMM_TILE")) : 0;   // 128 / 256: A/B aid
     const bool fits256 = (M % BM2 == 0) && (N % BN2 == 0);
     // the 256^2 kernel runs one workgroup per CU: it needs enough tiles to occupy the chip
     const bool big = (long long)(M / BM2) * (N / BN2) >= 128;
-    if (fits256 && (force == 256 || (force == 0 && big))) {
-        switch (epi) {
-            case EPI_BIAS_BF16: return launch_gemm256<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
-            case EPI_BIAS_GELU_BF16: return launch_gemm256<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);
-            case EPI_BIAS_RESID_F32: return launch_gemm256<EPI_BIAS_RESID_F32>(A, W, M, N, K, bias, out, st);
-            case EPI_STORE_F32: return launch_gemm256<EPI_STORE_F32>(A, W, M, N, K, bias, out, st);
-            case EPI_BIAS_F32: return launch_gemm256<EPI_BIAS_F32>(A, W, M, N, K, bias, out, st);
-            case EPI_BIAS_GELU_ERF_BF16: return launch_gemm256<EPI_BIAS_GELU_ERF_BF16>(A, W, M, N, K, bias, out, st);
-            default: return launch_gemm256<EPI_BIAS_TANH_BF16>(A, W, M, N, K, bias, out, st);
-        }
-    }
+    const bool use256 = fits256 && (force == 256 || (force == 0 && big));
+#define MMR_GEMM_CASE(E)                                                                         \
+    case E: return use256 ? launch_gemm256<E>(A, W, M, N, K, bias, out, aux, st)                 \
+                          : launch_gemm128<E>(A, W, M, N, K, bias, out, aux, st);
     switch (epi) {
-        case EPI_BIAS_BF16: return launch_gemm128<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
-        case EPI_BIAS_GELU_BF16: return launch_gemm128<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);
-        case EPI_BIAS_RESID_F32: return launch_gemm128<EPI_BIAS_RESID_F32>(A, W, M, N, K, bias, out, st);
-        case EPI_STORE_F32: return launch_gemm128<EPI_STORE_F32>(A, W, M, N, K, bias, out, st);
-        case EPI_BIAS_F32: return launch_gemm128<EPI_BIAS_F32>(A, W, M, N, K, bias, out, st);
-        case EPI_BIAS_GELU_ERF_BF16: return launch_gemm128<EPI_BIAS_GELU_ERF_BF16>(A, W, M, N, K, bias, out, st);
-        default: return launch_gemm128<EPI_BIAS_TANH_BF16>(A, W, M, N, K, bias, out, st);
+        MMR_GEMM_CASE(EPI_BIAS_BF16)
+        MMR_GEMM_CASE(EPI_BIAS_GELU_BF16)
+        MMR_GEMM_CASE(EPI_BIAS_RESID_F32)
+        MMR_GEMM_CASE(EPI_STORE_F32)
+        MMR_GEMM_CASE(EPI_BIAS_F32)
+        MMR_GEMM_CASE(EPI_BIAS_GELU_ERF_BF16)
+        MMR_GEMM_CASE(EPI_BIAS_TANH_BF16)
+        MMR_GEMM_CASE(EPI_LNFOLD_BF16)
+        MMR_GEMM_CASE(EPI_LNFOLD_GELU_BF16)
+        MMR_GEMM_CASE(EPI_RESID_STATS_F32)
     }
+#undef MMR_GEMM_CASE
+    return MMR_EINVAL;
+}
+
+int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
+                hipStream_t st)
+{
+    if (epi >= EPI_LNFOLD_BF16) { set_error("gemm: epilogue %d needs launch_gemm_aux", epi); return MMR_EINVAL; }
+    return launch_gemm_aux(epi, A, W, M, N, K, bias, out, GemmAux{}, st);
 }
 
 }  // namespace mmr

@@ -40,6 +40,55 @@ __device__ __forceinline__ double wave_sum_f64_butterfly(double v) {
     return v;
 }
 
+// sum over each aligned group of 16 lanes (a DPP "row"), result in every lane of the group:
+// quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- plain VALU, no LDS round trip
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));
+    return v;
+}
+
+// Per-launch extras of the LayerNorm-folding GEMM epilogues (gemm.hip).  Row statistics travel as
+// `np` partial (sum, sum of squares) pairs per row -- one per 64-column slab of the producer -- and are
+// added up in a fixed order by the consumer, so results do not depend on workgroup scheduling.
+struct GemmAux {
+    const float *colsum;     // LNFOLD: c[n] = sum_k W'[n,k] of the gamma-folded weight
+    const float2 *stats_in;  // LNFOLD: [M][np] partial (sum, sumsq) of the LayerNorm input rows
+    float2 *stats_out;       // RESID_STATS: [M][N/64] partials of the new residual rows
+    bf16_t *xout;            // RESID_STATS: bf16 copy of the new residual rows
+    int np;                  // LNFOLD: partials per row (= K / 64)
+    float inv_d, eps;        // 1 / width, LayerNorm epsilon
+};
+
+// LNFOLD prologue, two threads per tile row (blockDim = 2 * tile rows): thread t adds partials t&1, (t&1)+2, ... of
+// row t>>1 in index order, the pair is combined with one DPP swap, and (mean, rstd) lands in LDS for the
+// epilogue.  The loads are issued before the first K-tile is staged, so their latency hides under it.
+constexpr int LNFOLD_MAX_NP = 16;
+struct LnfoldLoads { float2 v[LNFOLD_MAX_NP / 2]; };
+__device__ __forceinline__ void lnfold_issue(const GemmAux &aux, int m0, LnfoldLoads &ld)
+{
+    const int t = threadIdx.x;
+    const float2 *p = aux.stats_in + (size_t)(m0 + (t >> 1)) * aux.np;
+#pragma unroll
+    for (int i = 0; i < LNFOLD_MAX_NP / 2; ++i) {
+        const int j = (t & 1) + 2 * i;
+        ld.v[i] = j < aux.np ? p[j] : make_float2(0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void lnfold_finish(const GemmAux &aux, const LnfoldLoads &ld, float2 *lds_stats)
+{
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNFOLD_MAX_NP / 2; ++i) { s += ld.v[i].x; ss += ld.v[i].y; }
+    s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, false));
+    ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0xB1, 0xf, 0xf, false));
+    const float mean = s * aux.inv_d;
+    const float rstd = rsqrtf(fmaxf(ss * aux.inv_d - mean * mean, 0.f) + aux.eps);
+    if (!(threadIdx.x & 1)) lds_stats[threadIdx.x >> 1] = make_float2(mean, rstd);
+}
+
 // async global -> LDS, 16 B per lane; LDS destination = wave-uniform base + lane*16
 __device__ __forceinline__ void glds16(const void *gsrc, void *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,

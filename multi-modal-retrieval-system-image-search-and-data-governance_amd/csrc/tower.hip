@@ -12,12 +12,14 @@
 namespace mmr {
 // gemm.hip
 enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_STORE_F32 = 3,
-       EPI_BIAS_F32 = 4, EPI_BIAS_GELU_ERF_BF16 = 5, EPI_BIAS_TANH_BF16 = 6 };
+       EPI_BIAS_F32 = 4, EPI_BIAS_GELU_ERF_BF16 = 5, EPI_BIAS_TANH_BF16 = 6, EPI_LNFOLD_BF16 = 7, EPI_LNFOLD_GELU_BF16 = 8,
+       EPI_RESID_STATS_F32 = 9 };
 int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st);
+int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, const GemmAux &aux, hipStream_t st);
 // vit_ops.hip
 int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P, int G, int K, int Kpad, hipStream_t st);
-int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h, int B, int T, int d, float eps, hipStream_t st);
-int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab, hipStream_t st);
+int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h, int B, int T, int d, float eps, bf16_t *xb, float2 *stats, hipStream_t st);
+int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab, bf16_t *xb, float2 *stats, hipStream_t st);
 int launch_layernorm(const float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps, hipStream_t st);
 int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const float *b, bf16_t *xc, int Nb, int T, int d, float eps, hipStream_t st);
 int launch_finish(const float *feat, void *out, mmr_dtype odt, int Nb, int E, int normalize, hipStream_t st);
@@ -42,6 +44,8 @@ static const char *validate_cfg(const mmr_tower_cfg *c)
     if (c->embed_dim < 128 || c->embed_dim % 128) return "embed_dim must be a positive multiple of 128";
     if (c->tokens < 1 || c->tokens > 608) return "tokens outside [1,608]";
     if (!(c->ln_eps > 0.f)) return "ln_eps must be > 0";
+    if (c->fold_ln != 0 && c->fold_ln != 1) return "fold_ln must be 0 or 1";
+    if (c->fold_ln && c->kind == 2) return "fold_ln is for pre-LN (CLIP) towers; BERT towers are post-LN";
     if (c->kind == 0) {
         if (c->patch < 1 || c->image_size < c->patch || c->image_size % c->patch) return "image_size must be a multiple of patch";
         const int g = c->image_size / c->patch;
@@ -101,12 +105,16 @@ static Layout make_layout(const mmr_tower_cfg &c)
     put(L.layer0[MMR_P_FC1_B], m * 4);
     put(L.layer0[MMR_P_FC2_W], d * m * 2);
     put(L.layer0[MMR_P_FC2_B], d * 4);
+    if (c.fold_ln) {
+        put(L.layer0[MMR_P_QKV_C], 3 * d * 4);
+        put(L.layer0[MMR_P_FC1_C], m * 4);
+    }
     L.layer_stride = off - l0;
     L.total = l0 + L.layer_stride * c.layers;
     return L;
 }
 
-static bool is_layer_param(int p) { return p >= MMR_P_LN1_W && p <= MMR_P_FC2_B; }
+static bool is_layer_param(int p) { return (p >= MMR_P_LN1_W && p <= MMR_P_FC2_B) || p == MMR_P_QKV_C || p == MMR_P_FC1_C; }
 
 }  // namespace mmr
 
@@ -136,6 +144,7 @@ extern "C" int mmr_tower_param_span(const mmr_tower_cfg *cfg, int param, int lay
     const Layout L = make_layout(*cfg);
     if (is_layer_param(param)) {
         MMR_CHECK_ARG(layer >= 0 && layer < cfg->layers, "mmr_tower_param_span: layer %d outside [0,%d)", layer, cfg->layers);
+        MMR_CHECK_ARG(L.layer0[param].bytes != 0, "mmr_tower_param_span: this tower has no tensor %d", param);
         *offset = L.layer0[param].off + (size_t)layer * L.layer_stride;
         *bytes = L.layer0[param].bytes;
     } else {
@@ -168,7 +177,7 @@ extern "C" void mmr_tower_destroy(mmr_tower *t) { delete t; }
 namespace {
 struct WsPlan {
     int M, Mpad, Mp, Mp_pad, Bpad;
-    size_t off_h, off_x, off_big, off_pe, off_xc, off_feat, total;
+    size_t off_h, off_x, off_big, off_pe, off_xc, off_feat, off_xo, off_stats, total;
 };
 WsPlan plan_ws(const mmr_tower_cfg &c, int B)
 {
@@ -193,6 +202,10 @@ WsPlan plan_ws(const mmr_tower_cfg &c, int B)
     put(p.off_pe, c.kind == 0 ? (size_t)p.Mp_pad * d * 4 : 0);
     put(p.off_xc, (size_t)p.Bpad * d * 2);
     put(p.off_feat, (size_t)p.Bpad * c.embed_dim * 4);
+    if (c.fold_ln) {
+        put(p.off_xo, (size_t)p.Mpad * d * 2);                 // attention output (x holds bf16(h))
+        put(p.off_stats, (size_t)p.Mpad * (d / 64) * 8);       // per-row (sum, sumsq) partials
+    }
     p.total = off;
     return p;
 }
@@ -232,6 +245,10 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
     const int d = c.width, T = c.tokens, E = c.embed_dim, m = c.mlp;
     const size_t hbytes = (size_t)p.M * d * sizeof(float);
     int rc;
+    const bool fold = c.fold_ln != 0;
+    bf16_t *xo = fold ? (bf16_t *)(ws + p.off_xo) : x;
+    float2 *stats = fold ? (float2 *)(ws + p.off_stats) : nullptr;
+    bf16_t *xb = fold ? x : nullptr;
 
     // ---- embeddings
     if (c.kind == 0) {
@@ -239,15 +256,28 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
         if ((rc = launch_im2col(input, in_dtype, big, B, c.image_size, c.patch, G, K, Kp, st))) return rc;
         if ((rc = launch_gemm(EPI_STORE_F32, big, t->g<bf16_t>(MMR_P_PATCH_W), p.Mp_pad, d, Kp, nullptr, pe, st))) return rc;
         if ((rc = launch_embed_vision(pe, t->g<float>(MMR_P_CLS), t->g<float>(MMR_P_POS), t->g<float>(MMR_P_LN_PRE_W),
-                                      t->g<float>(MMR_P_LN_PRE_B), h, B, T, d, c.ln_eps, st))) return rc;
+                                      t->g<float>(MMR_P_LN_PRE_B), h, B, T, d, c.ln_eps, xb, stats, st))) return rc;
     } else {
         if ((rc = launch_embed_text((const int32_t *)input, t->g<bf16_t>(MMR_P_TOK_EMB), t->g<float>(MMR_P_POS), h, B, T, d,
-                                    c.vocab, st))) return rc;
+                                    c.vocab, xb, stats, st))) return rc;
     }
     if (tap && tap_after == -1) MMR_CHECK_HIP(hipMemcpyAsync(tap, h, hbytes, hipMemcpyDeviceToDevice, st));
 
     // ---- transformer blocks (pre-LN; modeling_clip.py:362-383)
-    for (int i = 0; i < c.layers; ++i) {
+    for (int i = 0; i < c.layers && fold; ++i) {
+        // x = bf16(h) and `stats` always describe the current residual rows; LN1/LN2 live in the QKV/FC1 epilogues
+        GemmAux a{};
+        a.stats_in = stats; a.stats_out = stats; a.xout = x; a.np = d / 64; a.inv_d = 1.f / (float)d; a.eps = c.ln_eps;
+        a.colsum = t->l<float>(MMR_P_QKV_C, i);
+        if ((rc = launch_gemm_aux(EPI_LNFOLD_BF16, x, t->l<bf16_t>(MMR_P_QKV_W, i), p.Mpad, 3 * d, d, t->l<float>(MMR_P_QKV_B, i), big, a, st))) return rc;
+        if ((rc = launch_attention(big, xo, B, T, c.heads, d, c.kind == 1, st))) return rc;
+        if ((rc = launch_gemm_aux(EPI_RESID_STATS_F32, xo, t->l<bf16_t>(MMR_P_OUT_W, i), p.Mpad, d, d, t->l<float>(MMR_P_OUT_B, i), h, a, st))) return rc;
+        a.colsum = t->l<float>(MMR_P_FC1_C, i);
+        if ((rc = launch_gemm_aux(EPI_LNFOLD_GELU_BF16, x, t->l<bf16_t>(MMR_P_FC1_W, i), p.Mpad, m, d, t->l<float>(MMR_P_FC1_B, i), big, a, st))) return rc;
+        if ((rc = launch_gemm_aux(EPI_RESID_STATS_F32, big, t->l<bf16_t>(MMR_P_FC2_W, i), p.Mpad, d, m, t->l<float>(MMR_P_FC2_B, i), h, a, st))) return rc;
+        if (tap && tap_after == i) MMR_CHECK_HIP(hipMemcpyAsync(tap, h, hbytes, hipMemcpyDeviceToDevice, st));
+    }
+    for (int i = 0; i < c.layers && !fold; ++i) {
         if ((rc = launch_layernorm(h, t->l<float>(MMR_P_LN1_W, i), t->l<float>(MMR_P_LN1_B, i), x, p.M, d, c.ln_eps, st))) return rc;
         if ((rc = launch_gemm(EPI_BIAS_BF16, x, t->l<bf16_t>(MMR_P_QKV_W, i), p.Mpad, 3 * d, d, t->l<float>(MMR_P_QKV_B, i), big, st))) return rc;
         if ((rc = launch_attention(big, x, B, T, c.heads, d, c.kind == 1, st))) return rc;

@@ -79,12 +79,31 @@ __device__ __forceinline__ void ln_row(float (&x)[VPL], const float *__restrict_
     }
 }
 
+// LN-fold producers (tower.hip, fold_ln): alongside h emit x = bf16(h) and the row's (sum, sumsq) in the
+// partial-sum layout the GEMM epilogue reads (mmr_common.h GemmAux): partial 0 carries the row, the rest are 0.
+template <int VPL>
+__device__ __forceinline__ void emit_fold_inputs(const float (&x)[VPL], int lane, int64_t row, int d, bf16_t *__restrict__ xb,
+                                                 float2 *__restrict__ stats)
+{
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        s += x[j];
+        ss += x[j] * x[j];
+        xb[(size_t)row * d + j * 64 + lane] = f32_to_bf16(x[j]);
+    }
+    s = wave_sum(s);
+    ss = wave_sum(ss);
+    if (lane < VPL) stats[(size_t)row * VPL + lane] = lane == 0 ? make_float2(s, ss) : make_float2(0.f, 0.f);
+}
+
 // h[b*T + t] = LN_pre( (t == 0 ? cls : pe[b*G*G + t-1]) + pos[t] )        (fp32 residual stream)
 template <int VPL>
 __global__ __launch_bounds__(256) void embed_vision_kernel(const float *__restrict__ pe, const float *__restrict__ cls,
                                                            const float *__restrict__ pos, const float *__restrict__ lw,
                                                            const float *__restrict__ lb, float *__restrict__ h, int B,
-                                                           int T, int d, float eps)
+                                                           int T, int d, float eps, bf16_t *__restrict__ xb,
+                                                           float2 *__restrict__ stats)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -98,13 +117,15 @@ __global__ __launch_bounds__(256) void embed_vision_kernel(const float *__restri
     ln_row<VPL>(x, lw, lb, lane, d, eps);
 #pragma unroll
     for (int j = 0; j < VPL; ++j) h[(size_t)row * d + j * 64 + lane] = x[j];
+    if (xb) emit_fold_inputs<VPL>(x, lane, row, d, xb, stats);
 }
 
 // h[n*T + t] = tok[ids[n,t]] + pos[t]
 template <int VPL>
 __global__ __launch_bounds__(256) void embed_text_kernel(const int32_t *__restrict__ ids, const bf16_t *__restrict__ tok,
                                                          const float *__restrict__ pos, float *__restrict__ h, int Nb,
-                                                         int T, int d, int vocab)
+                                                         int T, int d, int vocab, bf16_t *__restrict__ xb,
+                                                         float2 *__restrict__ stats)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -112,11 +133,14 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int32_t *__restri
     const int t = (int)(row % T);
     int id = ids[row];
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // ids are validated on the host; clamp is a memory guard
+    float x[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         const int col = j * 64 + lane;
-        h[(size_t)row * d + col] = bf16_to_f32(tok[(size_t)id * d + col]) + pos[(size_t)t * d + col];
+        x[j] = bf16_to_f32(tok[(size_t)id * d + col]) + pos[(size_t)t * d + col];
+        h[(size_t)row * d + col] = x[j];
     }
+    if (xb) emit_fold_inputs<VPL>(x, lane, row, d, xb, stats);
 }
 
 // x_bf16[row] = LN(h[row])
@@ -546,21 +570,21 @@ int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P,
 }
 
 int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h,
-                        int B, int T, int d, float eps, hipStream_t st)
+                        int B, int T, int d, float eps, bf16_t *xb, float2 *stats, hipStream_t st)
 {
     ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)(((int64_t)B * T + 3) / 4));
-    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_vision_kernel<VPL>, grid, dim3(256), 0, st, pe, cls, pos, lw, lb, h, B, T, d, eps));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_vision_kernel<VPL>, grid, dim3(256), 0, st, pe, cls, pos, lw, lb, h, B, T, d, eps, xb, stats));
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
 
 int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab,
-                      hipStream_t st)
+                      bf16_t *xb, float2 *stats, hipStream_t st)
 {
     ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)(((int64_t)Nb * T + 3) / 4));
-    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_text_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, h, Nb, T, d, vocab));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_text_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, h, Nb, T, d, vocab, xb, stats));
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }

@@ -113,18 +113,23 @@ def test_attention_core(L, device, T, causal):
 
 
 # ------------------------------------------------------------------ tower-level
-def _tower(ccfg, w, device, kind):
+def _tower(ccfg, w, device, kind, fold=False):
     from mmr_amd.clip import _Tower
-    return _Tower(ccfg.vision if kind == "v" else ccfg.text, w, device)
+    return _Tower(ccfg.vision if kind == "v" else ccfg.text, w, device, fold_ln=fold)
 
 
-def test_tiny_vision_stages_vs_golden_and_oracle(L, device, golden_dir):
+# fold=True: LayerNorm folded into the QKV / FC1 GEMM epilogues (mmr_tower_cfg.fold_ln) -- same bounds
+FOLD = pytest.mark.parametrize("fold", [False, True], ids=["ln", "ln-folded"])
+
+
+@FOLD
+def test_tiny_vision_stages_vs_golden_and_oracle(L, device, golden_dir, fold):
     from oracle import clip_ref
     g = np.load(os.path.join(golden_dir, "encoder_tiny-test.npz"))
     ccfg = mmr_amd.get_config("tiny-test")
     w = weights.make_clip_weights(ccfg, seed=int(g["weight_seed"]))
     px = synth.synth_images(int(g["n_img"]), ccfg.vision.image_size, seed=int(g["image_seed"]))
-    tower = _tower(ccfg, w, device, "v")
+    tower = _tower(ccfg, w, device, "v", fold)
     B, T, d = px.shape[0], ccfg.vision.tokens, ccfg.vision.width
     # the device path rounds pixels to bf16 for the patch GEMM: give the oracle the same values
     st = {}
@@ -144,13 +149,14 @@ def test_tiny_vision_stages_vs_golden_and_oracle(L, device, golden_dir):
     assert _cos(feat, torch.from_numpy(g["image_features"])).min().item() >= 1 - 1e-3
 
 
-def test_tiny_text_vs_golden_and_oracle(L, device, golden_dir):
+@FOLD
+def test_tiny_text_vs_golden_and_oracle(L, device, golden_dir, fold):
     from oracle import clip_ref
     g = np.load(os.path.join(golden_dir, "encoder_tiny-test.npz"))
     ccfg = mmr_amd.get_config("tiny-test")
     w = weights.make_clip_weights(ccfg, seed=int(g["weight_seed"]))
     ids = synth.synth_token_ids(int(g["n_txt"]), ccfg.text.tokens, ccfg.text.vocab, seed=int(g["text_seed"]))
-    tower = _tower(ccfg, w, device, "t")
+    tower = _tower(ccfg, w, device, "t", fold)
     N, T, d = ids.shape[0], ccfg.text.tokens, ccfg.text.width
     st = {}
     with torch.no_grad():
@@ -166,9 +172,10 @@ def test_tiny_text_vs_golden_and_oracle(L, device, golden_dir):
 
 @pytest.mark.parametrize("name,fn", [("ViT-B/32", "encoder_ViT-B-32.npz"), ("ViT-L/14", "encoder_ViT-L-14.npz"),
                                      ("ViT-L/14@336px", "encoder_ViT-L-14_336px.npz")])
-def test_full_models_vs_hf_golden(device, golden_dir, name, fn):
+@FOLD
+def test_full_models_vs_hf_golden(device, golden_dir, name, fn, fold):
     g = np.load(os.path.join(golden_dir, fn))
-    model, _ = mmr_amd.load(name, device=device, seed=int(g["weight_seed"]))
+    model, _ = mmr_amd.load(name, device=device, seed=int(g["weight_seed"]), fold_ln=fold)
     assert model.dtype == torch.float32
     ccfg = model.cfg
     px = synth.synth_images(int(g["n_img"]), ccfg.vision.image_size, seed=int(g["image_seed"]))
@@ -239,11 +246,12 @@ def test_call_surface_like_reference_scripts(device):
     assert torch.equal(a, b)
 
 
-def test_batch_256_vitb32_matches_oracle_on_sample(device):
+@FOLD
+def test_batch_256_vitb32_matches_oracle_on_sample(device, fold):
     """BASELINE cfg2 shape (B=256, ViT-B/32 bf16): every row finite, rows independent of batch position,
     and a sample of rows checked against the fp32 oracle."""
     from oracle import clip_ref
-    model, _ = mmr_amd.load("ViT-B/32", device=device)
+    model, _ = mmr_amd.load("ViT-B/32", device=device, fold_ln=fold)
     model.bfloat16()
     px = synth.synth_images(256, 224, seed=2)
     f = model.encode_image(px.to(device), normalize=True)

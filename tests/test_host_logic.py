@@ -208,3 +208,43 @@ def test_feature_cache_formats_round_trip(tmp_path):
     f4, l4 = gallery.load_split_features(str(tmp_path / "c"), "val")
     assert torch.equal(f4, feats.float()) and torch.equal(l4, labels)
     assert [b.shape[0] for b in gallery.batched(list(range(10)), lambda i: torch.zeros(3, 4, 4), 4)] == [4, 4, 2]
+
+
+def test_fold_layernorm_identity():
+    """Host-side weight folding for mmr_tower_cfg.fold_ln: rstd*(h@W'^T - mean*c) + b' equals LN(h)@W^T + b."""
+    from mmr_amd.clip import fold_layernorm
+    g = torch.Generator().manual_seed(5)
+    d, n = 128, 192
+    W = (torch.randn(n, d, generator=g) * 0.05).bfloat16().float()
+    b = torch.randn(n, generator=g) * 0.02
+    gamma = 1 + 0.1 * torch.randn(d, generator=g)
+    beta = 0.05 * torch.randn(d, generator=g)
+    h = torch.randn(7, d, generator=g) * 3 + 0.5
+    Wf, bf, c = fold_layernorm(W, b, gamma, beta)
+    assert Wf.dtype == torch.bfloat16 and bf.shape == (n,) and c.shape == (n,)
+    assert torch.equal(c, Wf.double().sum(1).float())            # row sums of the ROUNDED folded weight
+    mean = h.double().mean(1, keepdim=True)
+    var = h.double().var(1, unbiased=False, keepdim=True)
+    rstd = (var + 1e-5).rsqrt()
+    folded = rstd * (h.double() @ Wf.double().t() - mean * c.double()) + bf.double()
+    ref = torch.nn.functional.layer_norm(h.double(), (d,), gamma.double(), beta.double(), 1e-5) @ W.double().t() + b.double()
+    # the only difference is the bf16 rounding of W*gamma (2^-9 relative per weight)
+    assert (folded - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item()
+
+
+def test_fold_ln_layout_adds_column_sums():
+    from mmr_amd import _lib
+    from mmr_amd.clip import _tower_cfg_struct
+    ccfg = mmr_amd.get_config("tiny-test")
+    L = _lib.lib()
+    plain, fold = _tower_cfg_struct(ccfg.vision), _tower_cfg_struct(ccfg.vision, fold_ln=True)
+    d, m = ccfg.vision.width, ccfg.vision.mlp
+    extra = ccfg.vision.layers * (((3 * d * 4 + 255) // 256 + (m * 4 + 255) // 256) * 256)
+    assert L.mmr_tower_weights_bytes(ctypes.byref(fold)) == L.mmr_tower_weights_bytes(ctypes.byref(plain)) + extra
+    off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+    assert L.mmr_tower_param_span(ctypes.byref(fold), _lib.P_QKV_C, 1, ctypes.byref(off), ctypes.byref(nb)) == 0
+    assert nb.value == 3 * d * 4
+    assert L.mmr_tower_param_span(ctypes.byref(plain), _lib.P_QKV_C, 0, ctypes.byref(off), ctypes.byref(nb)) != 0
+    bert = _lib.TowerCfg(kind=2, width=128, layers=2, heads=2, mlp=512, tokens=64, embed_dim=128, vocab=1000,
+                         ln_eps=1e-12, fold_ln=1)
+    assert L.mmr_tower_weights_bytes(ctypes.byref(bert)) == 0      # post-LN towers cannot fold
