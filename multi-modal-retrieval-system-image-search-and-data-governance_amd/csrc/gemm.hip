@@ -240,49 +240,53 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
                 *reinterpret_cast<uint2 *>(aux.xout + grow * N + col_base + rc * 4) = pk;
                 const float s1 = row16_sum((v.x + v.y) + (v.z + v.w));
                 const float s2 = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
-                if (rc == 0) aux.stats_out[grow * (N >> 6) + (col_base >> 6)] = make_float2(s1, s2);
+                if (rc == 0) emit_row_partial(aux.stats_out, grow, col_base >> 6, N >> 6, s1, s2);
             }
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// 256x256x64 tile, 8 waves (2 along M x 4 along N), each wave a 128x64 sub-tile = 32 accumulators.
+// 256 x (64*NIW) x 64 tile, 8 waves (2 along M x 4 along N), each wave a 128 x (16*NIW) sub-tile.
+//   NIW = 4: 256x256 tile, 32 accumulators per wave.   NIW = 3: 256x192 tile, 24 accumulators.
 // Operand fetch per CU, not MFMA issue, bounds the 128^2 kernel on these shapes (both structures
 // settle near the same ~17 B/clk/CU of L2->LDS traffic), so the lever is FLOPs per fetched byte:
-// this tile does 2x the work per byte.  Pipeline: every K-tile is 4 phases of 16 MFMAs (one
-// 64x32 quadrant of the wave's sub-tile over K=64); each phase reads its fragments, stages one
-// 16 KiB half-tile (A rows 0-127 / 128-255, W rows 0-127 / 128-255) of a FUTURE K-tile by
-// global_load_lds (LOAD segment), then runs its MFMA cluster (COMPUTE segment); segments are
-// separated by raw s_barriers and the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD)
-// run staggered by one segment, so LDS reads of one hide under the MFMAs of the other.  Half-tiles
-// are staged in the rotating order W0,W1,A0,A1 so each lands 3-6 phases before its first read; the
-// only wait on the load queue is a counted vmcnt(4) once per K-tile (never 0 inside the loop), two
-// barriers before the first read of the data it retires.
+// this tile does 2x the work per byte.  The 192-wide variant exists for tile-count quantisation:
+// N = 768 at M = 12800 is 150 tiles of 256x256 -- 59 % of the 256 CUs for one round -- but 200 tiles of
+// 256x192 (78 %), each 3/4 of the work (launch_gemm_aux picks by rounds x tile width).
+// Pipeline: every K-tile is 2 phases of 8*NIW MFMAs (one 64-row half of the wave's sub-tile over K=64);
+// each phase reads its fragments and stages two pieces of a FUTURE K-tile by global_load_lds (LOAD
+// segment), then runs its MFMA cluster (COMPUTE segment); segments are separated by raw s_barriers and
+// the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) run staggered by one segment, so
+// LDS reads of one hide under the MFMAs of the other.  Pieces are staged in the rotating order
+// W0,W1,A0,A1 (A0/A1 = tile rows 0-127 / 128-255; W0 = W rows 0-127, W1 = the remaining 128 or 64 rows)
+// so each lands 1.5-3 K-tiles before its first read; the only wait on the load queue is one counted
+// vmcnt per K-tile (never 0 inside the loop), two barriers before the first read of the data it retires.
+// Tried and dropped (measured slower on MI355X): 4 phases of 16 MFMAs per K-tile (more barrier overhead),
+// issuing one of the two stages between the MFMA clusters (-8 %), a 3-deep LDS ring.
 // ---------------------------------------------------------------------------------------------
-#ifndef MMR_GEMM_PHASES
-#define MMR_GEMM_PHASES 2
-#endif
-#ifndef MMR_GEMM_SPLIT_STAGE
-#define MMR_GEMM_SPLIT_STAGE 0   // measured: issuing half of the LDS-DMA inside the COMPUTE segment is 8% SLOWER
-#endif
-constexpr int BM2 = 256, BN2 = 256;
+constexpr int BM2 = 256;
 constexpr int GEMM2_THREADS = 512;
 constexpr int HALF_BYTES = 128 * BK * 2;            // 16 KiB: 128 rows x 64 bf16
-constexpr int STAGE2_BYTES = 4 * HALF_BYTES;        // A0 A1 W0 W1
+constexpr int STAGE2_BYTES = 4 * HALF_BYTES;        // A0 A1 W (up to 256 rows, contiguous image)
 constexpr int GEMM2_LDS = 2 * STAGE2_BYTES;         // 128 KiB
 
-template <int EPI>
+template <int EPI, int NIW>
 __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
     const float *__restrict__ bias, void *__restrict__ out, GemmAux aux)
 {
+    static_assert(NIW == 3 || NIW == 4, "tile width 192 or 256");
+    constexpr int BNT = 64 * NIW;                 // tile columns
+    constexpr int WCOLS = 16 * NIW;               // columns per wave
+    constexpr int W1_LOADS = NIW == 4 ? 2 : 1;    // global_load_lds per wave for piece W1 (128 or 64 rows)
+    constexpr int W_LOADS = 2 + W1_LOADS;         // ... for W0 + W1: the queue depth the counted wait leaves
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int gn = N / BN2;
+    const int gn = N / BNT;
     const int nblk = gridDim.x;
     int bid = blockIdx.x;
     {
@@ -290,63 +294,66 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
     }
     const int m0 = (bid / gn) * BM2;
-    const int n0 = (bid % gn) * BN2;
+    const int n0 = (bid % gn) * BNT;
 
-    // ---- staging: a half-tile is 16 blocks of 8 rows (1 KiB); wave w issues blocks 2w, 2w+1
+    // ---- staging: a 128-row piece is 16 blocks of 8 rows (1 KiB each); wave w issues blocks 2w, 2w+1.
+    // The 64-row W1 of the 192-wide tile is 8 blocks, one per wave.
     const int rr = lane >> 3;
     const int sc = (lane & 7) ^ rr;
-    const bf16_t *a_src = A + (size_t)(m0 + wave * 16 + rr) * K + sc * 8;   // + half*128 rows, + i*8 rows, + kt*64
+    const bf16_t *a_src = A + (size_t)(m0 + wave * 16 + rr) * K + sc * 8;   // + half*128 rows, + 8 rows, + kt*64
     const bf16_t *w_src = W + (size_t)(n0 + wave * 16 + rr) * K + sc * 8;
+    const bf16_t *w1_src = W + (size_t)(n0 + 128 + wave * 8 + rr) * K + sc * 8;   // NIW == 3 only
     const int nkt = K / BK;
     // kind: 0 = W0, 1 = W1, 2 = A0, 3 = A1  (the rotating stream order)
     auto stage = [&](int kt, int kind) {
         if (kt >= nkt) return;
         const int half = kind & 1;
         const bool isA = kind >= 2;
+        char *dst = smem + (kt & 1) * STAGE2_BYTES + ((isA ? 0 : 2) + half) * HALF_BYTES;
+        if (NIW == 3 && kind == 1) {
+            glds16(w1_src + (size_t)kt * BK, dst + wave * 1024);
+            return;
+        }
         const bf16_t *src = (isA ? a_src : w_src) + (size_t)half * 128 * K + (size_t)kt * BK;
-        char *dst = smem + (kt & 1) * STAGE2_BYTES + ((isA ? 0 : 2) + half) * HALF_BYTES + wave * 2048;
-        glds16(src, dst);
-        glds16(src + (size_t)8 * K, dst + 1024);
+        glds16(src, dst + wave * 2048);
+        glds16(src + (size_t)8 * K, dst + wave * 2048 + 1024);
     };
 
-    f32x4 acc[4][8];  // [ni][mi]
+    f32x4 acc[NIW][8];  // [ni][mi]
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < NIW; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
-    // per-lane fragment byte offsets inside a half-tile image (rows of this wave)
-    const int a_half = wr;                        // A half-tile this wave reads
-    const int w_half = wc >> 1;                   // W half-tile this wave reads
-    const int w_row0 = (wc & 1) * 64;
+    const int w_row0 = wc * WCOLS;                // this wave's rows inside the contiguous W tile image
 
     // prologue: stream elements 0..5 = W0,W1,A0,A1 of tile 0 and W0,W1 of tile 1
     float2 *row_stats = reinterpret_cast<float2 *>(smem + GEMM2_LDS);   // LNFOLD only: (mean, rstd) of the BM2 tile rows
     LnfoldLoads ld;
     if constexpr (epi_lnfold(EPI)) lnfold_issue(aux, m0, ld);
     stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
-    if (nkt > 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+    if (nkt > 1) wait_vmcnt<W_LOADS>(); else wait_vmcnt<0>();
     if constexpr (epi_lnfold(EPI)) lnfold_finish(aux, ld, row_stats);
     __builtin_amdgcn_s_barrier();
     // Stagger: waves 4-7 (wr == 1, the SIMD partners of waves 0-3) run one segment behind, so on every
     // SIMD one wave is in a LOAD segment (ds_read + global_load_lds) while its partner is in a COMPUTE
-    // segment (16 MFMAs).  Every wave executes the same number of barriers (compensated after the loop).
+    // segment.  Every wave executes the same number of barriers (compensated after the loop).
     if (wr == 1) __builtin_amdgcn_s_barrier();
 
-    bf16x8 af[4][2], wf[2][2][2];   // af[mi][ks];  wf[nh][ni][ks]
+    bf16x8 af[4][2], wf[NIW][2];   // af[mi][ks];  wf[ni][ks]
 #define MMR_LOAD_DONE()  do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
     for (int kt = 0; kt < nkt; ++kt) {
         const char *sb = smem + (kt & 1) * STAGE2_BYTES;
-        const char *ta = sb + a_half * HALF_BYTES;
-        const char *tw = sb + (2 + w_half) * HALF_BYTES;
+        const char *ta = sb + wr * HALF_BYTES;        // the A half-tile this wave reads
+        const char *tw = sb + 2 * HALF_BYTES;
 
-        auto read_w = [&](int nh) {
+        auto read_w = [&]() {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
-                    wf[nh][ni][ks] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(w_row0 + nh * 32 + ni * 16 + fr, ks * 4 + fg));
+                    wf[ni][ks] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(w_row0 + ni * 16 + fr, ks * 4 + fg));
         };
         auto read_a = [&](int mh) {
 #pragma unroll
@@ -355,81 +362,36 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
                 for (int ks = 0; ks < 2; ++ks)
                     af[mi][ks] = *reinterpret_cast<const bf16x8 *>(ta + tile_off(mh * 64 + mi * 16 + fr, ks * 4 + fg));
         };
-        auto mma = [&](int mh, int nh) {
+        auto mma = [&](int mh) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int ni = 0; ni < NIW; ++ni)
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
-                        acc[nh * 2 + ni][mh * 4 + mi] =
-                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nh][ni][ks], af[mi][ks], acc[nh * 2 + ni][mh * 4 + mi], 0, 0, 0);
+                        acc[ni][mh * 4 + mi] =
+                            __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][ks], af[mi][ks], acc[ni][mh * 4 + mi], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         };
 
-#if MMR_GEMM_PHASES == 4
-        // phase 0: quadrant (m-half 0, n-half 0); stage A0 of tile kt+1
-        read_w(0); read_a(0);
+        // phase A: rows 0-63 of the wave's sub-tile: reads W (all of the wave's columns) + A rows 0-63;
+        // stages A0, A1 of tile kt+1
+        read_w(); read_a(0);
         stage(kt + 1, 2);
-        MMR_LOAD_DONE();
-        mma(0, 0);
-        __builtin_amdgcn_s_barrier();
-        // phase 1: quadrant (0, 1); stage A1 of tile kt+1
-        read_w(1);
         stage(kt + 1, 3);
         MMR_LOAD_DONE();
-        mma(0, 1);
+        mma(0);
         __builtin_amdgcn_s_barrier();
-        // phase 2: quadrant (1, 1); stage W0 of tile kt+2 (W of tile kt was last read in phase 1)
+        // phase B: rows 64-127: reads A rows 64-127; stages W0, W1 of tile kt+2 (W of tile kt was last
+        // read in phase A); retires tile kt+1's pieces (youngest staged in phase A of this tile)
         read_a(1);
         stage(kt + 2, 0);
-        MMR_LOAD_DONE();
-        mma(1, 1);
-        __builtin_amdgcn_s_barrier();
-        // phase 3: quadrant (1, 0); stage W1 of tile kt+2; retire tile kt+1's four half-tiles (the
-        // youngest of them was staged in phase 1) two barriers before the other group's first read
         stage(kt + 2, 1);
-        if (kt + 2 < nkt) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        if (kt + 2 < nkt) wait_vmcnt<W_LOADS>(); else wait_vmcnt<0>();
         MMR_LOAD_DONE();
-        mma(1, 0);
+        mma(1);
         __builtin_amdgcn_s_barrier();
-#else
-        // Two phases per K-tile, 32 MFMAs each (fewer, longer segments: less barrier overhead).  Both
-        // half-tile stages of a phase are issued in its LOAD segment; MMR_GEMM_SPLIT_STAGE=1 moves one of
-        // them between the two MFMA clusters of the COMPUTE segment (an A/B knob: measured 8% slower --
-        // the main loop already runs within ~10% of the MFMA issue rate at the sustained clock).
-        // phase A: quadrants (0,0) (0,1): reads W both n-halves + A m-half 0; stages A0, A1 of tile kt+1
-        read_w(0); read_w(1); read_a(0);
-        stage(kt + 1, 2);
-#if !MMR_GEMM_SPLIT_STAGE
-        stage(kt + 1, 3);
-#endif
-        MMR_LOAD_DONE();
-        mma(0, 0);
-#if MMR_GEMM_SPLIT_STAGE
-        stage(kt + 1, 3);
-#endif
-        mma(0, 1);
-        __builtin_amdgcn_s_barrier();
-        // phase B: quadrants (1,1) (1,0): reads A m-half 1; stages W0, W1 of tile kt+2 (W of tile kt was
-        // last read in phase A); retires tile kt+1's half-tiles (youngest staged in phase A of this tile)
-        read_a(1);
-        stage(kt + 2, 0);
-#if MMR_GEMM_SPLIT_STAGE
-        if (kt + 2 < nkt) wait_vmcnt<2>(); else wait_vmcnt<0>();
-#else
-        stage(kt + 2, 1);
-        if (kt + 2 < nkt) wait_vmcnt<4>(); else wait_vmcnt<0>();
-#endif
-        MMR_LOAD_DONE();
-        mma(1, 1);
-#if MMR_GEMM_SPLIT_STAGE
-        stage(kt + 2, 1);
-#endif
-        mma(1, 0);
-        __builtin_amdgcn_s_barrier();
-#endif
     }
 #undef MMR_LOAD_DONE
     if (wr == 0) __builtin_amdgcn_s_barrier();
@@ -438,7 +400,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     {
         float keep = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NIW; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) keep += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
         if (keep == 123.456f) ((float *)out)[0] = keep;
@@ -448,11 +410,12 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     // ---- epilogue.  In the accumulator layout a lane owns 4 consecutive columns of 16 different rows,
     // so direct stores touch 16 rows x 32 B per instruction (measured: 14-33 us per GEMM, a third of
     // the kernel).  The staging LDS is idle now (the loop's last barriers retired every read), so each
-    // wave transposes its own 128x64 sub-tile through a PRIVATE 16 KiB region (no barrier needed) and
-    // stores whole 128-byte (bf16) / 256-byte (fp32) row segments, 16 B per lane.
+    // wave transposes its own sub-tile through a PRIVATE 16 KiB region (no barrier needed) and stores
+    // whole row segments (128 or 96 B bf16 / 256 or 192 B fp32), 16 B per lane.  The LDS image keeps the
+    // 8- / 16-chunk row pitch for both widths, so the XOR swizzle stays inside a row.
     char *my = smem + wave * 16384;
     const size_t row_base = (size_t)(m0 + wr * 128);
-    const int col_base = n0 + wc * 64;
+    const int col_base = n0 + wc * WCOLS;
     if constexpr (epi_bf16(EPI)) {
         // image: [128 rows][8 chunks of 8 bf16], chunk index XOR (row & 7)
         float mean[8], rstd[8];
@@ -464,7 +427,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
             }
         }
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NIW; ++ni) {
             const float4 b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
             float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (epi_lnfold(EPI)) c4 = *reinterpret_cast<const float4 *>(aux.colsum + col_base + ni * 16 + fg * 4);
@@ -486,19 +449,22 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
             }
         }
         const int rc = lane & 7, rr0 = lane >> 3;
+        if (rc < 2 * NIW) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int row = i * 8 + rr0;
-            const uint4 v = *reinterpret_cast<const uint4 *>(my + row * 128 + ((rc ^ (row & 7)) << 4));
-            *reinterpret_cast<uint4 *>((bf16_t *)out + (row_base + row) * N + col_base + rc * 8) = v;
+            for (int i = 0; i < 16; ++i) {
+                const int row = i * 8 + rr0;
+                const uint4 v = *reinterpret_cast<const uint4 *>(my + row * 128 + ((rc ^ (row & 7)) << 4));
+                *reinterpret_cast<uint4 *>((bf16_t *)out + (row_base + row) * N + col_base + rc * 8) = v;
+            }
         }
     } else {
         // fp32: two passes of 64 rows; image [64 rows][16 chunks of 4 floats], chunk index XOR (row & 15)
         const int rc = lane & 15, rr0 = lane >> 4;
+        const bool live = rc < 4 * NIW;
 #pragma unroll
         for (int mh = 0; mh < 2; ++mh) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < NIW; ++ni) {
                 float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (epi_bias(EPI)) b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
                 const int c = ni * 4 + fg;
@@ -513,40 +479,45 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = i * 4 + rr0;
-                float4 v = *reinterpret_cast<const float4 *>(my + row * 256 + ((rc ^ (row & 15)) << 4));
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 const size_t grow = row_base + mh * 64 + row;
-                float4 *dst = reinterpret_cast<float4 *>((float *)out + grow * N + col_base + rc * 4);
-                if constexpr (epi_resid(EPI)) {
-                    const float4 h = *dst;
-                    v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+                if (live) {
+                    v = *reinterpret_cast<const float4 *>(my + row * 256 + ((rc ^ (row & 15)) << 4));
+                    float4 *dst = reinterpret_cast<float4 *>((float *)out + grow * N + col_base + rc * 4);
+                    if constexpr (epi_resid(EPI)) {
+                        const float4 h = *dst;
+                        v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
+                    }
+                    *dst = v;
                 }
-                *dst = v;
                 if constexpr (EPI == EPI_RESID_STATS_F32) {
-                    uint2 pk;
-                    pk.x = pack_bf16x2(v.x, v.y);
-                    pk.y = pack_bf16x2(v.z, v.w);
-                    *reinterpret_cast<uint2 *>(aux.xout + grow * N + col_base + rc * 4) = pk;
+                    if (live) {
+                        uint2 pk;
+                        pk.x = pack_bf16x2(v.x, v.y);
+                        pk.y = pack_bf16x2(v.z, v.w);
+                        *reinterpret_cast<uint2 *>(aux.xout + grow * N + col_base + rc * 4) = pk;
+                    }
                     const float s1 = row16_sum((v.x + v.y) + (v.z + v.w));
                     const float s2 = row16_sum((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
-                    if (rc == 0) aux.stats_out[grow * (N >> 6) + (col_base >> 6)] = make_float2(s1, s2);
+                    if (rc == 0) emit_row_partial(aux.stats_out, grow, col_base / WCOLS, N / WCOLS, s1, s2);
                 }
             }
         }
     }
 }
 
-template <int EPI>
+template <int EPI, int NIW>
 static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
                           const GemmAux &aux, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<EPI>),
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<EPI, NIW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS + BM2 * 8));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm256_bf16_kernel<EPI>, dim3((M / BM2) * (N / BN2)), dim3(GEMM2_THREADS), GEMM2_LDS + BM2 * 8, st, A, W, M, N,
-                       K, bias, out, aux);
+    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, NIW>), dim3((M / BM2) * (N / (64 * NIW))), dim3(GEMM2_THREADS),
+                       GEMM2_LDS + BM2 * 8, st, A, W, M, N, K, bias, out, aux);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
@@ -577,20 +548,34 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
         return MMR_EINVAL;
     }
     if (epi < 0 || epi >= EPI_COUNT) { set_error("gemm: unknown epilogue %d", epi); return MMR_EINVAL; }
-    if (epi_lnfold(epi) && (aux.np != K / 64 || aux.np > LNFOLD_MAX_NP || !aux.stats_in || !aux.colsum)) {
-        set_error("gemm: LN-fold epilogue needs K/64 = %d <= %d row-stat partials, stats and column sums", K / 64, LNFOLD_MAX_NP);
-        return MMR_EINVAL;
-    }
+    if (epi_lnfold(epi) && (!aux.stats_in || !aux.colsum)) { set_error("gemm: LN-fold epilogue needs row stats and column sums"); return MMR_EINVAL; }
     if (epi == EPI_RESID_STATS_F32 && (!aux.stats_out || !aux.xout)) { set_error("gemm: RESID_STATS epilogue needs stats_out and xout"); return MMR_EINVAL; }
     ProfScope prof(MMR_PROF_GEMM, st);
-    static const int force = getenv("MMR_GEMM_TILE") ? atoi(getenv("MMR_GEMM_TILE")) : 0;   // 128 / 256: A/B aid
-    const bool fits256 = (M % BM2 == 0) && (N % BN2 == 0);
-    // the 256^2 kernel runs one workgroup per CU: it needs enough tiles to occupy the chip
-    const bool big = (long long)(M / BM2) * (N / BN2) >= 128;
-    const bool use256 = fits256 && (force == 256 || (force == 0 && big));
-#define MMR_GEMM_CASE(E)                                                                         \
-    case E: return use256 ? launch_gemm256<E>(A, W, M, N, K, bias, out, aux, st)                 \
-                          : launch_gemm128<E>(A, W, M, N, K, bias, out, aux, st);
+    static const int force = getenv("MMR_GEMM_TILE") ? atoi(getenv("MMR_GEMM_TILE")) : 0;   // 128 / 192 / 256: A/B aid
+    // Tile choice.  The 256-row kernels run one workgroup per CU: they need enough tiles to occupy the chip, and
+    // among the two widths the cheaper is the one with fewer (rounds over 256 CUs) x (tile width).
+    const int cus = 256;
+    auto cost = [&](int bn) -> long long {
+        if (M % BM2 || N % bn) return -1;
+        const long long tiles = (long long)(M / BM2) * (N / bn);
+        if (tiles < 128) return -1;
+        return (tiles + cus - 1) / cus * bn;
+    };
+    const long long c256 = cost(256), c192 = cost(192);
+    int tile = 128;
+    if (c256 > 0) tile = 256;
+    if (c192 > 0 && (c256 < 0 || c192 < c256)) tile = 192;
+    if (force == 128) tile = 128;
+    if (force == 256 && M % BM2 == 0 && N % 256 == 0) tile = 256;
+    if (force == 192 && M % BM2 == 0 && N % 192 == 0) tile = 192;
+    if (epi == EPI_RESID_STATS_F32 && N / (tile == 192 ? 48 : 64) > LNFOLD_NP) {
+        set_error("gemm: RESID_STATS row of %d columns needs more than %d partial slots", N, LNFOLD_NP);
+        return MMR_EINVAL;
+    }
+#define MMR_GEMM_CASE(E)                                                                                   \
+    case E: return tile == 256   ? launch_gemm256<E, 4>(A, W, M, N, K, bias, out, aux, st)                 \
+                   : tile == 192 ? launch_gemm256<E, 3>(A, W, M, N, K, bias, out, aux, st)                 \
+                                 : launch_gemm128<E>(A, W, M, N, K, bias, out, aux, st);
     switch (epi) {
         MMR_GEMM_CASE(EPI_BIAS_BF16)
         MMR_GEMM_CASE(EPI_BIAS_GELU_BF16)

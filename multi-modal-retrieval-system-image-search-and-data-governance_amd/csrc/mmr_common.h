@@ -51,37 +51,42 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 
 // Per-launch extras of the LayerNorm-folding GEMM epilogues (gemm.hip).  Row statistics travel as
-// `np` partial (sum, sum of squares) pairs per row -- one per 64-column slab of the producer -- and are
-// added up in a fixed order by the consumer, so results do not depend on workgroup scheduling.
+// LNFOLD_NP partial (sum, sum of squares) slots per row: a producer whose row is covered by S column slabs
+// (one per wave column) fills slot `slab` and zeroes slots slab+S, slab+2S, ...; the consumer adds all
+// LNFOLD_NP slots in a fixed order, so results do not depend on workgroup scheduling or on the tile width
+// the producer happened to run with.
+constexpr int LNFOLD_NP = 16;
 struct GemmAux {
     const float *colsum;     // LNFOLD: c[n] = sum_k W'[n,k] of the gamma-folded weight
-    const float2 *stats_in;  // LNFOLD: [M][np] partial (sum, sumsq) of the LayerNorm input rows
-    float2 *stats_out;       // RESID_STATS: [M][N/64] partials of the new residual rows
+    const float2 *stats_in;  // LNFOLD: [M][LNFOLD_NP] partial (sum, sumsq) of the LayerNorm input rows
+    float2 *stats_out;       // RESID_STATS: [M][LNFOLD_NP] partials of the new residual rows
     bf16_t *xout;            // RESID_STATS: bf16 copy of the new residual rows
-    int np;                  // LNFOLD: partials per row (= K / 64)
     float inv_d, eps;        // 1 / width, LayerNorm epsilon
 };
 
-// LNFOLD prologue, two threads per tile row (blockDim = 2 * tile rows): thread t adds partials t&1, (t&1)+2, ... of
+__device__ __forceinline__ void emit_row_partial(float2 *stats, size_t row, int slab, int nslabs, float s, float ss)
+{
+    float2 *p = stats + row * LNFOLD_NP;
+    p[slab] = make_float2(s, ss);
+    for (int j = slab + nslabs; j < LNFOLD_NP; j += nslabs) p[j] = make_float2(0.f, 0.f);
+}
+
+// LNFOLD prologue, two threads per tile row (blockDim = 2 * tile rows): thread t adds slots t&1, (t&1)+2, ... of
 // row t>>1 in index order, the pair is combined with one DPP swap, and (mean, rstd) lands in LDS for the
 // epilogue.  The loads are issued before the first K-tile is staged, so their latency hides under it.
-constexpr int LNFOLD_MAX_NP = 16;
-struct LnfoldLoads { float2 v[LNFOLD_MAX_NP / 2]; };
+struct LnfoldLoads { float2 v[LNFOLD_NP / 2]; };
 __device__ __forceinline__ void lnfold_issue(const GemmAux &aux, int m0, LnfoldLoads &ld)
 {
     const int t = threadIdx.x;
-    const float2 *p = aux.stats_in + (size_t)(m0 + (t >> 1)) * aux.np;
+    const float2 *p = aux.stats_in + (size_t)(m0 + (t >> 1)) * LNFOLD_NP + (t & 1);
 #pragma unroll
-    for (int i = 0; i < LNFOLD_MAX_NP / 2; ++i) {
-        const int j = (t & 1) + 2 * i;
-        ld.v[i] = j < aux.np ? p[j] : make_float2(0.f, 0.f);
-    }
+    for (int i = 0; i < LNFOLD_NP / 2; ++i) ld.v[i] = p[2 * i];
 }
 __device__ __forceinline__ void lnfold_finish(const GemmAux &aux, const LnfoldLoads &ld, float2 *lds_stats)
 {
     float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < LNFOLD_MAX_NP / 2; ++i) { s += ld.v[i].x; ss += ld.v[i].y; }
+    for (int i = 0; i < LNFOLD_NP / 2; ++i) { s += ld.v[i].x; ss += ld.v[i].y; }
     s += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s), 0xB1, 0xf, 0xf, false));
     ss += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, ss), 0xB1, 0xf, 0xf, false));
     const float mean = s * aux.inv_d;

@@ -204,7 +204,7 @@ WsPlan plan_ws(const mmr_tower_cfg &c, int B)
     put(p.off_feat, (size_t)p.Bpad * c.embed_dim * 4);
     if (c.fold_ln) {
         put(p.off_xo, (size_t)p.Mpad * d * 2);                 // attention output (x holds bf16(h))
-        put(p.off_stats, (size_t)p.Mpad * (d / 64) * 8);       // per-row (sum, sumsq) partials
+        put(p.off_stats, (size_t)p.Mpad * LNFOLD_NP * 8);      // per-row (sum, sumsq) partial slots
     }
     p.total = off;
     return p;
@@ -267,7 +267,7 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
     for (int i = 0; i < c.layers && fold; ++i) {
         // x = bf16(h) and `stats` always describe the current residual rows; LN1/LN2 live in the QKV/FC1 epilogues
         GemmAux a{};
-        a.stats_in = stats; a.stats_out = stats; a.xout = x; a.np = d / 64; a.inv_d = 1.f / (float)d; a.eps = c.ln_eps;
+        a.stats_in = stats; a.stats_out = stats; a.xout = x; a.inv_d = 1.f / (float)d; a.eps = c.ln_eps;
         a.colsum = t->l<float>(MMR_P_QKV_C, i);
         if ((rc = launch_gemm_aux(EPI_LNFOLD_BF16, x, t->l<bf16_t>(MMR_P_QKV_W, i), p.Mpad, 3 * d, d, t->l<float>(MMR_P_QKV_B, i), big, a, st))) return rc;
         if ((rc = launch_attention(big, xo, B, T, c.heads, d, c.kind == 1, st))) return rc;

@@ -80,7 +80,7 @@ __device__ __forceinline__ void ln_row(float (&x)[VPL], const float *__restrict_
 }
 
 // LN-fold producers (tower.hip, fold_ln): alongside h emit x = bf16(h) and the row's (sum, sumsq) in the
-// partial-sum layout the GEMM epilogue reads (mmr_common.h GemmAux): partial 0 carries the row, the rest are 0.
+// partial-sum layout the GEMM epilogue reads (mmr_common.h GemmAux): slot 0 carries the row, the rest are 0.
 template <int VPL>
 __device__ __forceinline__ void emit_fold_inputs(const float (&x)[VPL], int lane, int64_t row, int d, bf16_t *__restrict__ xb,
                                                  float2 *__restrict__ stats)
@@ -94,7 +94,7 @@ __device__ __forceinline__ void emit_fold_inputs(const float (&x)[VPL], int lane
     }
     s = wave_sum(s);
     ss = wave_sum(ss);
-    if (lane < VPL) stats[(size_t)row * VPL + lane] = lane == 0 ? make_float2(s, ss) : make_float2(0.f, 0.f);
+    if (lane < LNFOLD_NP) stats[(size_t)row * LNFOLD_NP + lane] = lane == 0 ? make_float2(s, ss) : make_float2(0.f, 0.f);
 }
 
 // h[b*T + t] = LN_pre( (t == 0 ? cls : pe[b*G*G + t-1]) + pos[t] )        (fp32 residual stream)

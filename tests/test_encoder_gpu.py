@@ -31,7 +31,9 @@ def _cos(a, b):
 # ------------------------------------------------------------------ kernel-level
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 128), (1280, 2304, 768), (384, 768, 3072),
                                    (256, 256, 64), (512, 256, 128), (256, 768, 192), (4096, 1024, 256),
-                                   (12800, 768, 768)])
+                                   (12800, 768, 768),       # 256x192 tiles (200 tiles beat 150 of 256x256)
+                                   (8192, 768, 128),        # 256x192 tiles, exactly 128 of them
+                                   (12800, 1024, 128)])     # 256x256 tiles
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_epilogues(L, device, M, N, K, epi):
     g = torch.Generator().manual_seed(M + N + K + epi)
@@ -257,7 +259,13 @@ def test_batch_256_vitb32_matches_oracle_on_sample(device, fold):
     f = model.encode_image(px.to(device), normalize=True)
     assert f.dtype == torch.bfloat16 and f.shape == (256, 512) and torch.isfinite(f.float()).all()
     f1 = model.encode_image(px[100:104].to(device), normalize=True)
-    assert torch.equal(f[100:104], f1)                       # no cross-image leakage, deterministic
+    if fold:
+        # folded LayerNorm statistics are summed per wave column slab, whose width follows the GEMM tile the
+        # batch size selects: rows agree across batch sizes to rounding, not bit for bit
+        assert _cos(f[100:104].float(), f1.float()).min().item() >= 1 - 1e-4
+        assert torch.equal(f, model.encode_image(px.to(device), normalize=True))     # still run-to-run deterministic
+    else:
+        assert torch.equal(f[100:104], f1)                   # no cross-image leakage, deterministic
     w = weights.make_clip_weights(model.cfg)
     with torch.no_grad():
         ref = clip_ref.l2_normalize(clip_ref.encode_image(w, model.cfg.vision, px[[0, 255]].bfloat16().float()))

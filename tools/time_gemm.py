@@ -9,6 +9,8 @@ L = _lib.lib()
 st = _lib.stream_ptr(dev)
 shapes = [("qkv", 0, 12800, 2304, 768), ("out", 2, 12800, 768, 768), ("fc1", 1, 12800, 3072, 768),
           ("fc2", 2, 12800, 768, 3072), ("patch", 3, 12544, 768, 3072)]
+if os.environ.get("SHAPES"):      # "name:epi:M:N:K,..."
+    shapes = [(a, int(b), int(c), int(d), int(e)) for a, b, c, d, e in (x.split(":") for x in os.environ["SHAPES"].split(","))]
 tot = 0.0
 for name, epi, M, N, K in shapes:
     A = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
