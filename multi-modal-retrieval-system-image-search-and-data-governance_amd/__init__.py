@@ -36,7 +36,7 @@ def __getattr__(name):
 
         mod = importlib.import_module(f"{__name__}.{_LAZY[name]}")
         return getattr(mod, name)
-    if name in ("synth", "weights", "search", "clip", "config", "_lib", "gallery", "preprocess", "bert", "tokenizer"):
+    if name in ("synth", "weights", "search", "clip", "config", "_lib", "gallery", "preprocess", "bert", "tokenizer", "checkpoint"):
         import importlib
 
         return importlib.import_module(f"{__name__}.{name}")

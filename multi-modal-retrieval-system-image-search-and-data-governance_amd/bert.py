@@ -129,9 +129,39 @@ class BertTextEncoder:
 
 
 def load_text_encoder(name: str = "IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chinese", device="cuda",
-                      weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0) -> BertTextEncoder:
-    """Counterpart of ``BertForSequenceClassification.from_pretrained(name)`` for the Taiyi text tower."""
-    cfg = get_bert_config(name)
+                      weights=None, seed: int = 0) -> BertTextEncoder:
+    """Counterpart of ``BertForSequenceClassification.from_pretrained(name)`` for the Taiyi text tower.
+    ``weights``: a checkpoint path (safetensors / state-dict .bin) or a state dict in HF or this package's
+    naming; ``name`` may also be a checkpoint file or a directory holding ``model.safetensors`` /
+    ``pytorch_model.bin`` (the from_pretrained layout).  Without any, seeded synthetic weights."""
+    import os
+
+    from . import checkpoint
+
+    path = weights if isinstance(weights, (str, os.PathLike)) else None
     if weights is None:
+        if os.path.isfile(name):
+            path = name
+        elif os.path.isdir(name):
+            for fn in ("model.safetensors", "pytorch_model.bin"):
+                if os.path.isfile(os.path.join(name, fn)):
+                    path = os.path.join(name, fn)
+                    break
+    if path is not None:
+        weights = checkpoint.read_state_dict(os.fspath(path))
+    if weights is not None:
+        kind, weights = checkpoint.convert_state_dict(weights)
+        if kind != "bert":
+            raise ValueError(f"checkpoint holds a {kind} model, not a BERT text encoder")
+        inferred = checkpoint.infer_bert_config(weights, os.path.basename(os.fspath(name)))
+        try:
+            cfg = get_bert_config(name)
+        except RuntimeError:
+            cfg = inferred
+        geom = lambda c: (c.width, c.layers, c.heads, c.mlp, c.max_positions, c.vocab, c.embed_dim)  # noqa: E731
+        if geom(cfg) != geom(inferred):
+            raise ValueError(f"checkpoint geometry {geom(inferred)} does not match {name} {geom(cfg)}")
+    else:
+        cfg = get_bert_config(name)
         weights = make_bert_weights(cfg, seed=seed)
     return BertTextEncoder(cfg, weights, device)

@@ -318,14 +318,47 @@ def _preprocess_factory(n_px: int, device: torch.device):
     return preprocess
 
 
+def _find_checkpoint(name: str, download_root: Optional[str]) -> Optional[str]:
+    """A checkpoint file for `name`: `name` itself if it is a file, else <download_root>/<ViT-B-32>.{safetensors,state.pt,pt,bin}
+    (the OpenAI package caches "ViT-B/32" as ViT-B-32.pt under download_root)."""
+    if os.path.isfile(name):
+        return name
+    if download_root:
+        stem = name.replace("/", "-").replace("@", "-")
+        for ext in (".safetensors", ".state.pt", ".pt", ".bin"):
+            cand = os.path.join(os.path.expanduser(download_root), stem + ext)
+            if os.path.isfile(cand):
+                return cand
+    return None
+
+
 def load(name: str = "ViT-B/32", device: Union[str, torch.device] = "cuda", jit: bool = False,
-         download_root: Optional[str] = None, weights: Optional[Dict[str, torch.Tensor]] = None, seed: int = 0,
+         download_root: Optional[str] = None, weights: Union[None, str, Dict[str, torch.Tensor]] = None, seed: int = 0,
          fold_ln: Optional[bool] = None):
-    """``clip.load`` signature.  No checkpoint can be fetched offline, so unless ``weights`` (a dict
-    in this repo's naming, see weights.py) is given, seeded synthetic weights of the named
-    architecture are generated -- the same tensors the golden fixtures were produced with."""
-    cfg = get_config(name)
-    if weights is None:
+    """``clip.load`` signature.  Weights come from, in order: ``weights`` (a checkpoint path, or a state dict in
+    OpenAI-CLIP, HF-CLIPModel or this package's naming -- checkpoint.py converts); a checkpoint file named by
+    ``name`` or found under ``download_root``; otherwise (nothing can be downloaded here) seeded synthetic
+    weights of the named architecture -- the same tensors the golden fixtures were produced with."""
+    from . import checkpoint
+
+    path = weights if isinstance(weights, (str, os.PathLike)) else (_find_checkpoint(name, download_root) if weights is None else None)
+    if path is not None:
+        weights = checkpoint.read_state_dict(os.fspath(path))
+    if weights is not None:
+        kind, weights = checkpoint.convert_state_dict(weights)
+        if kind != "clip":
+            raise ValueError(f"checkpoint holds a {kind} model; use load_text_encoder for BERT text towers")
+        inferred = checkpoint.infer_clip_config(weights, name)
+        try:
+            cfg = get_config(name)
+        except RuntimeError:
+            if not os.path.isfile(name):
+                raise
+            cfg = inferred
+        if (cfg.vision, cfg.text) != (inferred.vision, inferred.text):
+            raise ValueError(f"checkpoint geometry {inferred.vision} / {inferred.text} does not match {name}")
+    else:
+        cfg = get_config(name)
         weights = make_clip_weights(cfg, seed=seed)
     model = CLIP(cfg, weights, device, fold_ln=fold_ln)
     return model, _preprocess_factory(cfg.vision.image_size, model.device)
