@@ -274,7 +274,7 @@ constexpr int GEMM2_LDS = 2 * STAGE2_BYTES;         // 128 KiB
 template <int EPI, int NIW>
 __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
-    const float *__restrict__ bias, void *__restrict__ out, GemmAux aux)
+    const float *__restrict__ bias, void *__restrict__ out, GemmAux aux, int pg)
 {
     static_assert(NIW == 3 || NIW == 4, "tile width 192 or 256");
     constexpr int BNT = 64 * NIW;                 // tile columns
@@ -293,8 +293,14 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         const int qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
         bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
     }
-    const int m0 = (bid / gn) * BM2;
-    const int n0 = (bid % gn) * BNT;
+    // Tile order inside an XCD's contiguous range: groups of `pg` row panels, column-major inside a group, so the
+    // ~32 tiles an XCD runs at once share few A panels AND few W tiles (their union has to fit its 4 MiB L2;
+    // row-major order with N/BNT = 12 touches all of W every round and re-fetches it: 139 MB vs 24 MB of operands)
+    const int per_group = pg * gn;
+    const int grp = bid / per_group, rem = bid - grp * per_group;
+    const int rows_here = min(pg, M / BM2 - grp * pg);
+    const int m0 = (grp * pg + rem % rows_here) * BM2;
+    const int n0 = (rem / rows_here) * BNT;
 
     // ---- staging: a 128-row piece is 16 blocks of 8 rows (1 KiB each); wave w issues blocks 2w, 2w+1.
     // The 64-row W1 of the 192-wide tile is 8 blocks, one per wave.
@@ -516,8 +522,13 @@ static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS + BM2 * 8));
         attr_set = true;
     }
-    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, NIW>), dim3((M / BM2) * (N / (64 * NIW))), dim3(GEMM2_THREADS),
-                       GEMM2_LDS + BM2 * 8, st, A, W, M, N, K, bias, out, aux);
+    // panels per tile-order group: the concurrent set of one XCD (32 CUs) should be near-square, at most 6 columns wide
+    static const int force_pg = getenv("MMR_GEMM_PG") ? atoi(getenv("MMR_GEMM_PG")) : 0;
+    const int gn = N / (64 * NIW);
+    const int cols = gn < 6 ? gn : 6;
+    const int pg = force_pg > 0 ? force_pg : (32 + cols - 1) / cols;
+    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, NIW>), dim3((M / BM2) * gn), dim3(GEMM2_THREADS),
+                       GEMM2_LDS + BM2 * 8, st, A, W, M, N, K, bias, out, aux, pg);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
