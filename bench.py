@@ -62,6 +62,10 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+# BASELINE.json's metric string, verbatim
+METRIC = "images/sec encode + Mqueries/sec top-10 over 1M\u00d7512 gallery, 1\u21928 MI355X"
+
+
 def cpu_baseline(model_cfg, cores):
     """Bounded CPU sample on this box's host cores: the fp32 oracle for encode, the reference's torch
     expression for scoring + top-k.  Reported beside the GPU number; never part of it."""
@@ -212,7 +216,7 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "images/sec encode + Mqueries/sec top-10 over 1Mx512 gallery",
+            "metric": METRIC,
             "value": round(world * BATCH / (ms_per_step * 1e-3), 1),
             "unit": "images/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
