@@ -58,6 +58,28 @@ __device__ __forceinline__ float epi_act(float v) {
     }
 }
 
+// diagnostic build (-DMMR_GEMM_FOLDROWS): every tile stores into the first 256 output rows, so the stores stay in
+// L2 -- separates the epilogue's instruction cost from the HBM write burst (outputs are wrong)
+#ifdef MMR_GEMM_FOLDROWS
+#define MMR_OUT_ROW(r) ((r) & 255)
+#else
+#define MMR_OUT_ROW(r) (r)
+#endif
+// 16-byte epilogue store.  MMR_GEMM_NT_STORE=1 (A/B knob) marks it non-temporal.
+#ifndef MMR_GEMM_NT_STORE
+#define MMR_GEMM_NT_STORE 0
+#endif
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+template <typename V>
+__device__ __forceinline__ void epi_store16(void *dst, const V &v) {
+    static_assert(sizeof(V) == 16, "16-byte vector");
+#if MMR_GEMM_NT_STORE
+    __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), reinterpret_cast<u32x4_t *>(dst));
+#else
+    *reinterpret_cast<V *>(dst) = v;
+#endif
+}
+
 // byte offset of 16-B chunk `c` (0..7) of tile row `row` inside a [rows][64] bf16 tile image
 __device__ __forceinline__ int tile_off(int row, int c) {
     return (row >> 3) * 1024 + (row & 7) * 128 + ((c ^ (row & 7)) << 4);
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
         for (int i = 0; i < 8; ++i) {
             const int row = i * 8 + rr0;
             const uint4 v = *reinterpret_cast<const uint4 *>(my + row * 128 + ((rc ^ (row & 7)) << 4));
-            *reinterpret_cast<uint4 *>((bf16_t *)out + (row_base + row) * N + col_base + rc * 8) = v;
+            epi_store16((bf16_t *)out + (row_base + row) * N + col_base + rc * 8, v);
         }
     } else {
         char *my = smem + wave * 16384;          // [64 rows][16 chunks of 4 floats], chunk ^ (row & 15)
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
                 const float4 h = *dst;
                 v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
             }
-            *dst = v;
+            epi_store16(dst, v);
             if constexpr (EPI == EPI_RESID_STATS_F32) {
                 uint2 pk;
                 pk.x = pack_bf16x2(v.x, v.y);
@@ -460,7 +482,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
             for (int i = 0; i < 16; ++i) {
                 const int row = i * 8 + rr0;
                 const uint4 v = *reinterpret_cast<const uint4 *>(my + row * 128 + ((rc ^ (row & 7)) << 4));
-                *reinterpret_cast<uint4 *>((bf16_t *)out + (row_base + row) * N + col_base + rc * 8) = v;
+                epi_store16((bf16_t *)out + MMR_OUT_ROW(row_base + row) * N + col_base + rc * 8, v);
             }
         }
     } else {
@@ -494,7 +516,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
                         const float4 h = *dst;
                         v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
                     }
-                    *dst = v;
+                    epi_store16(dst, v);
                 }
                 if constexpr (EPI == EPI_RESID_STATS_F32) {
                     if (live) {
