@@ -184,6 +184,10 @@ class CLIP:
     def context_length(self) -> int:
         return self.cfg.text.tokens
 
+    @property
+    def vocab_size(self) -> int:
+        return self.cfg.text.vocab
+
     def eval(self):
         return self
 
