@@ -399,14 +399,27 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
 // ---------------------------------------------------------------------------------------------
 // attention core for long sequences (T = 257, 577: ViT-L/14): flash-style streaming.
 //   grid (ceil(T/64), heads, B); a workgroup owns 64 queries (one 16-query block per wave) and streams
-//   the head's keys/values in blocks of 64 through a double-buffered 34 KiB LDS image, so several
+//   the head's keys/values in blocks of 64 through a double-buffered 32 KiB LDS image, so several
 //   workgroups share a CU and the next block's global loads (issued to registers before the block's
 //   MFMAs, written to LDS after them) overlap the current block's compute.  Online softmax: running
-//   max per query, un-normalised bf16 P, one rescale of the 64x16 output tile per key block.
+//   max per query, un-normalised bf16 P, the 64x16 output tile rescaled only when a running max moved.
+//   K and V are both stored row-major [key][64 dims] with the XOR chunk swizzle; S^T = K.Q^T reads K rows
+//   with ds_read_b128, and O^T = V^T.P^T needs V column-wise (8 keys of one dim per lane), which gfx950's
+//   ds_read_b64_tr_b16 delivers straight from the row-major image (4 keys x 16 dims per 16-lane group,
+//   conflict-free on this image) -- no transposing 2-byte LDS writes.
+//   The softmax runs in the log2 domain on the raw dot products: q.k * (scale*log2e) - m, one FMA and one
+//   v_exp_f32 per score; keys past T are masked only in the last block.
 // ---------------------------------------------------------------------------------------------
 constexpr int AKB = 64;                       // keys per block
-constexpr int AV_STR = AKB * 2 + 8;           // bytes per V^T row (+8 breaks the power-of-two stride)
-constexpr int ABUF = AKB * 128 + 64 * AV_STR; // one buffer: K [64][64] bf16 + V^T [64][64(+4)] bf16
+constexpr int AIMG = AKB * 128;               // one [64 keys][64 dims] bf16 image
+constexpr int ABUF = 2 * AIMG;                // one buffer: K image + V image
+
+// 4 keys x 16 dims transposed read: each lane gets 4 consecutive keys of one dim (see header)
+__device__ __forceinline__ uint2 lds_read_tr16(const char *addr) {
+    uint2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)addr) : "memory");
+    return v;
+}
 
 template <bool CAUSAL>
 __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
@@ -420,6 +433,7 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
     const int fr = lane & 15, fg = lane >> 4;
     const int qi = (blockIdx.x * 4 + wave) * 16 + fr;      // this lane's query
     const int nkb = (T + AKB - 1) / AKB;
+    const float c2 = scale * 1.44269504088896341f;          // scores enter exp2 as s*c2 - m
 
     bf16x8 qf[2];
 #pragma unroll
@@ -443,19 +457,22 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
         }
     };
     auto lwrite = [&](int buf) {
-        char *Ks = smem + buf * ABUF, *Vt = Ks + AKB * 128;
+        char *Ks = smem + buf * ABUF, *Vs = Ks + AIMG;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + i * 256, row = id >> 3, c = id & 7;
-            *reinterpret_cast<uint4 *>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kreg[i];
-            const uint32_t w[4] = {vreg[i].x, vreg[i].y, vreg[i].z, vreg[i].w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<bf16_t *>(Vt + (c * 8 + e) * AV_STR + row * 2) = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
+            const int off = row * 128 + ((c ^ (row & 7)) << 4);
+            *reinterpret_cast<uint4 *>(Ks + off) = kreg[i];
+            *reinterpret_cast<uint4 *>(Vs + off) = vreg[i];
         }
     };
+    // transposed-read address of this lane inside a V image, for the block of keys r0..r0+3 (r0 = 4*fg here, + a
+    // multiple of 16 added as an immediate-like constant by the caller) and dims 16*dt..16*dt+15:
+    // lane 4q+p of its 16-lane group supplies key r0+q, dims 16*dt + 4p .. 4p+3
+    const int tq = fr >> 2, tp = fr & 3;
+    const int trow = 4 * fg + tq;                            // key row inside a 16-key group; (row & 7) = trow & 7
 
-    float m = -INFINITY, l = 0.f;             // running max (uniform over the 4 lanes of a query), partial sum
+    float m = -INFINITY, l = 0.f;             // running max in the exp2 domain (uniform over a query's 4 lanes), partial sum
     f32x4 oacc[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -466,7 +483,7 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
     for (int kb = 0; kb < nkb; ++kb) {
         const int buf = kb & 1;
         if (kb + 1 < nkb) gload(kb + 1);       // in flight during this block's MFMAs
-        const char *Ks = smem + buf * ABUF, *Vt = Ks + AKB * 128;
+        const char *Ks = smem + buf * ABUF, *Vs = Ks + AIMG;
 
         f32x4 sc[4];
 #pragma unroll
@@ -480,37 +497,43 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
             }
             sc[jt] = a;
         }
-        float bm = -INFINITY;
+        // keys past T (last block only) and, for the causal form, keys after the query
+        if (CAUSAL || kb == nkb - 1) {
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = kb * AKB + jt * 16 + fg * 4 + r;
-                float v = sc[jt][r] * scale;
-                if (key >= T || (CAUSAL && key > qi)) v = -INFINITY;
-                sc[jt][r] = v;
-                bm = fmaxf(bm, v);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb * AKB + jt * 16 + fg * 4 + r;
+                    if (key >= T || (CAUSAL && key > qi)) sc[jt][r] = -INFINITY;
+                }
+        }
+        float bm = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
+#pragma unroll
+        for (int jt = 1; jt < 4; ++jt) bm = fmaxf(bm, fmaxf(fmaxf(sc[jt][0], sc[jt][1]), fmaxf(sc[jt][2], sc[jt][3])));
         bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
         bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-        const float mn = fmaxf(m, bm);
+        const float mn = fmaxf(m, bm * c2);                   // scale > 0: max commutes with the scaling
         const float msafe = mn == -INFINITY ? 0.f : mn;       // fully masked so far (causal padding rows)
-        const float alpha = __expf(m - msafe);
+        const bool moved = mn != m;
+        const float alpha = __builtin_amdgcn_exp2f(m - msafe);
         m = mn;
         float ps = 0.f;
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[jt][r] - msafe);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[jt][r], c2, -msafe));
                 sc[jt][r] = p;
                 ps += p;
             }
-        l = l * alpha + ps;
+        if (__any(moved)) {                    // wave-uniform: rescale only when some query's running max moved
+            l *= alpha;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+                for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+        }
+        l += ps;
 
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
@@ -519,14 +542,19 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
             pf.u[1] = pack_bf16x2(sc[2 * s2][2], sc[2 * s2][3]);
             pf.u[2] = pack_bf16x2(sc[2 * s2 + 1][0], sc[2 * s2 + 1][1]);
             pf.u[3] = pack_bf16x2(sc[2 * s2 + 1][2], sc[2 * s2 + 1][3]);
+            // the MFMA's k slots 8*fg .. 8*fg+7 are keys 32*s2 + 4*fg + {0..3} and 32*s2 + 16 + 4*fg + {0..3}
+            union { bf16x8 v; uint2 h[2]; } vf[4];
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const char *vr = Vt + (dt * 16 + fr) * AV_STR + (32 * s2 + 4 * fg) * 2;
-                union { bf16x8 v; uint2 h[2]; } vf;
-                vf.h[0] = *reinterpret_cast<const uint2 *>(vr);
-                vf.h[1] = *reinterpret_cast<const uint2 *>(vr + 32);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, oacc[dt], 0, 0, 0);
+                const int r0 = 32 * s2 + trow;
+                const int ch = ((dt * 2 + (tp >> 1)) ^ (trow & 7)) << 4;      // (r0 + 16) & 7 == r0 & 7 == trow & 7
+                vf[dt].h[0] = lds_read_tr16(Vs + r0 * 128 + ch + 8 * (tp & 1));
+                vf[dt].h[1] = lds_read_tr16(Vs + (r0 + 16) * 128 + ch + 8 * (tp & 1));
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt].v, pf.v, oacc[dt], 0, 0, 0);
         }
         if (kb + 1 < nkb) lwrite(buf ^ 1);     // the other buffer was last read in iteration kb-1
         __syncthreads();
