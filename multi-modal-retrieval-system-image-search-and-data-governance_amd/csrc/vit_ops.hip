@@ -415,13 +415,35 @@ constexpr int AIMG = AKB * 128;               // one [64 keys][64 dims] bf16 ima
 constexpr int ABUF = 2 * AIMG;                // one buffer: K image + V image
 
 // 4 keys x 16 dims transposed read: each lane gets 4 consecutive keys of one dim (see header)
-__device__ __forceinline__ uint2 lds_read_tr16(const char *addr) {
-    uint2 v;
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));   // native vector types: asm operands stay in registers
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2_t lds_read_tr16(const char *addr) {
+    u32x2_t v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)addr) : "memory");
     return v;
 }
 
-template <bool CAUSAL>
+// QB = 16-query blocks per wave (1 or 2).  With QB = 2 every K row fragment and every transposed V read feeds two
+// MFMAs, which halves the LDS bytes per FLOP -- the limiter at QB = 1, where each wave re-reads the whole 16 KiB
+// K/V block for 16 queries -- at the price of 128-query workgroups (more padding when T mod 128 is small).
+// reduce over the 4 lanes that share a query (lane, lane^16, lane^32, lane^48) with gfx950's row swaps (plain VALU;
+// __shfl_xor would go through ds_bpermute and the LDS crossbar's latency)
+template <typename F>
+__device__ __forceinline__ float quad_rows_reduce(float v, F op) {
+#ifdef MMR_ATTN_SHFL
+    v = op(v, __shfl_xor(v, 16, 64));
+    return op(v, __shfl_xor(v, 32, 64));
+#endif
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // NB: read the two results as .x/.y through __uint_as_float.  __builtin_bit_cast(float, a[1]) on the returned
+    // ext-vector is miscompiled by ROCm 7.2 clang (element 0 is used for both: the ISA shows v_add v1, v1, v1).
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // rows 0<->1, 2<->3
+    v = op(__uint_as_float(a.x), __uint_as_float(a.y));
+    const u32x2 c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // halves
+    return op(__uint_as_float(c.x), __uint_as_float(c.y));
+}
+
+template <bool CAUSAL, int QB>
 __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
                                                                int T, int d, float scale)
 {
@@ -431,16 +453,18 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
     const size_t ld = (size_t)3 * d;
     const bf16_t *base = qkv + (size_t)b * T * ld + hd * 64;
     const int fr = lane & 15, fg = lane >> 4;
-    const int qi = (blockIdx.x * 4 + wave) * 16 + fr;      // this lane's query
+    const int q0 = (blockIdx.x * 4 + wave) * (16 * QB) + fr;   // this lane's first query; block x adds 16*x
     const int nkb = (T + AKB - 1) / AKB;
     const float c2 = scale * 1.44269504088896341f;          // scores enter exp2 as s*c2 - m
 
-    bf16x8 qf[2];
+    bf16x8 qf[QB][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        qf[s] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        if (qi < T) qf[s] = *reinterpret_cast<const bf16x8 *>(base + (size_t)qi * ld + s * 32 + fg * 8);
-    }
+    for (int x = 0; x < QB; ++x)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[x][s] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (q0 + 16 * x < T) qf[x][s] = *reinterpret_cast<const bf16x8 *>(base + (size_t)(q0 + 16 * x) * ld + s * 32 + fg * 8);
+        }
 
     // each thread moves 2 K chunks and 2 V chunks (16 B each) per key block
     uint4 kreg[2], vreg[2];
@@ -466,16 +490,20 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
             *reinterpret_cast<uint4 *>(Vs + off) = vreg[i];
         }
     };
-    // transposed-read address of this lane inside a V image, for the block of keys r0..r0+3 (r0 = 4*fg here, + a
-    // multiple of 16 added as an immediate-like constant by the caller) and dims 16*dt..16*dt+15:
-    // lane 4q+p of its 16-lane group supplies key r0+q, dims 16*dt + 4p .. 4p+3
+    // transposed-read address of this lane inside a V image: lane 4q+p of its 16-lane group supplies key r0+q,
+    // dims 16*dt + 4p .. 4p+3, for the block of keys r0 = 4*fg (+ a multiple of 16)
     const int tq = fr >> 2, tp = fr & 3;
     const int trow = 4 * fg + tq;                            // key row inside a 16-key group; (row & 7) = trow & 7
 
-    float m = -INFINITY, l = 0.f;             // running max in the exp2 domain (uniform over a query's 4 lanes), partial sum
-    f32x4 oacc[4];
+    float m[QB], l[QB];                       // running max in the exp2 domain (uniform over a query's 4 lanes), partial sum
+    f32x4 oacc[QB][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < QB; ++x) {
+        m[x] = -INFINITY;
+        l[x] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) oacc[x][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
 
     gload(0);
     lwrite(0);
@@ -485,91 +513,127 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
         if (kb + 1 < nkb) gload(kb + 1);       // in flight during this block's MFMAs
         const char *Ks = smem + buf * ABUF, *Vs = Ks + AIMG;
 
-        f32x4 sc[4];
+        f32x4 sc[QB][4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
-            f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
             const int row = jt * 16 + fr;
+            bf16x8 kf[2];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + row * 128 + (((s * 4 + fg) ^ (row & 7)) << 4));
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
+            for (int s = 0; s < 2; ++s)
+                kf[s] = *reinterpret_cast<const bf16x8 *>(Ks + row * 128 + (((s * 4 + fg) ^ (row & 7)) << 4));
+#pragma unroll
+            for (int x = 0; x < QB; ++x) {
+                f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < 2; ++s) a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[s], qf[x][s], a, 0, 0, 0);
+                sc[x][jt] = a;
             }
-            sc[jt] = a;
         }
-        // keys past T (last block only) and, for the causal form, keys after the query
-        if (CAUSAL || kb == nkb - 1) {
+        // V fragments for the whole block, issued now so their LDS latency hides under the softmax:
+        // the MFMA's k slots 8*fg .. 8*fg+7 are keys 32*s2 + 4*fg + {0..3} and 32*s2 + 16 + 4*fg + {0..3}
+        u32x2_t vraw[2][4][2];                 // [s2][dt][half]; not to be touched before the wait below
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kb * AKB + jt * 16 + fg * 4 + r;
-                    if (key >= T || (CAUSAL && key > qi)) sc[jt][r] = -INFINITY;
-                }
-        }
-        float bm = fmaxf(fmaxf(sc[0][0], sc[0][1]), fmaxf(sc[0][2], sc[0][3]));
-#pragma unroll
-        for (int jt = 1; jt < 4; ++jt) bm = fmaxf(bm, fmaxf(fmaxf(sc[jt][0], sc[jt][1]), fmaxf(sc[jt][2], sc[jt][3])));
-        bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-        bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-        const float mn = fmaxf(m, bm * c2);                   // scale > 0: max commutes with the scaling
-        const float msafe = mn == -INFINITY ? 0.f : mn;       // fully masked so far (causal padding rows)
-        const bool moved = mn != m;
-        const float alpha = __builtin_amdgcn_exp2f(m - msafe);
-        m = mn;
-        float ps = 0.f;
-#pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[jt][r], c2, -msafe));
-                sc[jt][r] = p;
-                ps += p;
-            }
-        if (__any(moved)) {                    // wave-uniform: rescale only when some query's running max moved
-            l *= alpha;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
-        }
-        l += ps;
-
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            union { bf16x8 v; uint32_t u[4]; } pf;
-            pf.u[0] = pack_bf16x2(sc[2 * s2][0], sc[2 * s2][1]);
-            pf.u[1] = pack_bf16x2(sc[2 * s2][2], sc[2 * s2][3]);
-            pf.u[2] = pack_bf16x2(sc[2 * s2 + 1][0], sc[2 * s2 + 1][1]);
-            pf.u[3] = pack_bf16x2(sc[2 * s2 + 1][2], sc[2 * s2 + 1][3]);
-            // the MFMA's k slots 8*fg .. 8*fg+7 are keys 32*s2 + 4*fg + {0..3} and 32*s2 + 16 + 4*fg + {0..3}
-            union { bf16x8 v; uint2 h[2]; } vf[4];
+        for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int r0 = 32 * s2 + trow;
                 const int ch = ((dt * 2 + (tp >> 1)) ^ (trow & 7)) << 4;      // (r0 + 16) & 7 == r0 & 7 == trow & 7
-                vf[dt].h[0] = lds_read_tr16(Vs + r0 * 128 + ch + 8 * (tp & 1));
-                vf[dt].h[1] = lds_read_tr16(Vs + (r0 + 16) * 128 + ch + 8 * (tp & 1));
+                vraw[s2][dt][0] = lds_read_tr16(Vs + r0 * 128 + ch + 8 * (tp & 1));
+                vraw[s2][dt][1] = lds_read_tr16(Vs + (r0 + 16) * 128 + ch + 8 * (tp & 1));
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
+        // keys past T (last block only) and, for the causal form, keys after the query
+        if (CAUSAL || kb == nkb - 1) {
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[dt].v, pf.v, oacc[dt], 0, 0, 0);
+            for (int x = 0; x < QB; ++x)
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kb * AKB + jt * 16 + fg * 4 + r;
+                        if (key >= T || (CAUSAL && key > q0 + 16 * x)) sc[x][jt][r] = -INFINITY;
+                    }
+        }
+        bool moved = false;
+        float alpha[QB];
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
+            float bm = fmaxf(fmaxf(sc[x][0][0], sc[x][0][1]), fmaxf(sc[x][0][2], sc[x][0][3]));
+#pragma unroll
+            for (int jt = 1; jt < 4; ++jt)
+                bm = fmaxf(bm, fmaxf(fmaxf(sc[x][jt][0], sc[x][jt][1]), fmaxf(sc[x][jt][2], sc[x][jt][3])));
+            bm = quad_rows_reduce(bm, [](float p, float q) { return fmaxf(p, q); });
+            const float mn = fmaxf(m[x], bm * c2);                // scale > 0: max commutes with the scaling
+            const float msafe = mn == -INFINITY ? 0.f : mn;       // fully masked so far (causal padding rows)
+            moved |= mn != m[x];
+            alpha[x] = __builtin_amdgcn_exp2f(m[x] - msafe);
+            m[x] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[x][jt][r], c2, -msafe));
+                    sc[x][jt][r] = p;
+                    ps += p;
+                }
+            l[x] = l[x] * alpha[x] + ps;
+        }
+        if (__any(moved)) {                    // wave-uniform: rescale only when some query's running max moved
+#pragma unroll
+            for (int x = 0; x < QB; ++x)
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) oacc[x][dt][r] *= alpha[x];
+        }
+        // The transposed V reads are invisible to the compiler's counters: wait for them, and re-define the raw
+        // registers at this point ("+v") so that no copy into the MFMA operand tuples can be scheduled before the
+        // data has landed.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+            asm volatile("" : "+v"(vraw[s2][0][0]), "+v"(vraw[s2][0][1]), "+v"(vraw[s2][1][0]), "+v"(vraw[s2][1][1]),
+                              "+v"(vraw[s2][2][0]), "+v"(vraw[s2][2][1]), "+v"(vraw[s2][3][0]), "+v"(vraw[s2][3][1]));
+        __builtin_amdgcn_sched_barrier(0);
+        bf16x8 vf[2][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                vf[s2][dt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vraw[s2][dt][0], vraw[s2][dt][1], 0, 1, 2, 3));
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            union { bf16x8 v; uint32_t u[4]; } pf[QB];
+#pragma unroll
+            for (int x = 0; x < QB; ++x) {
+                pf[x].u[0] = pack_bf16x2(sc[x][2 * s2][0], sc[x][2 * s2][1]);
+                pf[x].u[1] = pack_bf16x2(sc[x][2 * s2][2], sc[x][2 * s2][3]);
+                pf[x].u[2] = pack_bf16x2(sc[x][2 * s2 + 1][0], sc[x][2 * s2 + 1][1]);
+                pf[x].u[3] = pack_bf16x2(sc[x][2 * s2 + 1][2], sc[x][2 * s2 + 1][3]);
+            }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+                for (int x = 0; x < QB; ++x)
+                    oacc[x][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s2][dt], pf[x].v, oacc[x][dt], 0, 0, 0);
         }
         if (kb + 1 < nkb) lwrite(buf ^ 1);     // the other buffer was last read in iteration kb-1
         __syncthreads();
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    const float inv = 1.f / l;
-    if (qi < T) {
-        bf16_t *dst = o + ((size_t)b * T + qi) * d + hd * 64 + fg * 4;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            uint2 pk;
-            pk.x = pack_bf16x2(oacc[dt][0] * inv, oacc[dt][1] * inv);
-            pk.y = pack_bf16x2(oacc[dt][2] * inv, oacc[dt][3] * inv);
-            *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+    for (int x = 0; x < QB; ++x) {
+        const float lx = quad_rows_reduce(l[x], [](float p, float q) { return p + q; });
+        const float inv = 1.f / lx;
+        const int qi = q0 + 16 * x;
+        if (qi < T) {
+            bf16_t *dst = o + ((size_t)b * T + qi) * d + hd * 64 + fg * 4;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                uint2 pk;
+                pk.x = pack_bf16x2(oacc[x][dt][0] * inv, oacc[x][dt][1] * inv);
+                pk.y = pack_bf16x2(oacc[x][dt][2] * inv, oacc[x][dt][3] * inv);
+                *reinterpret_cast<uint2 *>(dst + dt * 16) = pk;
+            }
         }
     }
 }
@@ -698,9 +762,18 @@ int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int
     const int nt = (T + 31) / 32 * 2;
     if (nt > 6) {   // long sequences: streaming kernel
         ProfScope prof(MMR_PROF_ATTENTION, st);
-        const dim3 grid((T + 63) / 64, heads, Bn);
-        if (causal) hipLaunchKernelGGL(attention_stream_kernel<true>, grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
-        else hipLaunchKernelGGL(attention_stream_kernel<false>, grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+        // 32 queries per wave (128 per workgroup) unless that pads the sequence by more than 64-query workgroups would
+        static const int force_qb = getenv("MMR_ATTN_QB") ? atoi(getenv("MMR_ATTN_QB")) : 0;   // 1 / 2: A/B aid
+        const int pad128 = (T + 127) / 128 * 128, pad64 = (T + 63) / 64 * 64;
+        const int qb = force_qb ? force_qb : (pad128 == pad64 ? 2 : 1);
+        const dim3 grid(qb == 2 ? pad128 / 128 : pad64 / 64, heads, Bn);
+        if (causal) {
+            if (qb == 2) hipLaunchKernelGGL((attention_stream_kernel<true, 2>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+            else hipLaunchKernelGGL((attention_stream_kernel<true, 1>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+        } else {
+            if (qb == 2) hipLaunchKernelGGL((attention_stream_kernel<false, 2>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+            else hipLaunchKernelGGL((attention_stream_kernel<false, 1>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+        }
         MMR_CHECK_LAUNCH();
         return MMR_OK;
     }
