@@ -277,6 +277,37 @@ __global__ __launch_bounds__(256) void finish_kernel(const float *__restrict__ f
 }
 
 // ---------------------------------------------------------------------------------------------
+// attention helpers
+// ---------------------------------------------------------------------------------------------
+// ds_read_b64_tr_b16 (gfx950): per 16-lane group a 4-row x 16-column block of 16-bit elements, delivered column-major:
+// lane 4q+p of the group supplies the address of row q, columns 4p..4p+3; lane i receives column i of the 4 rows.
+// With V stored row-major [key][dim] this is the "8 keys of one dim per lane" operand of O^T = V^T.P^T for free.
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));   // native vector types: asm operands stay in registers
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2_t lds_read_tr16(const char *addr) {
+    u32x2_t v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)addr) : "memory");
+    return v;
+}
+
+// reduce over the 4 lanes that share a query (lane, lane^16, lane^32, lane^48) with gfx950's row swaps (plain VALU;
+// __shfl_xor would go through ds_bpermute and the LDS crossbar's latency)
+template <typename F>
+__device__ __forceinline__ float quad_rows_reduce(float v, F op) {
+#ifdef MMR_ATTN_SHFL
+    v = op(v, __shfl_xor(v, 16, 64));
+    return op(v, __shfl_xor(v, 32, 64));
+#endif
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    // NB: read the two results as .x/.y through __uint_as_float.  __builtin_bit_cast(float, a[1]) on the returned
+    // ext-vector is miscompiled by ROCm 7.2 clang (element 0 is used for both: the ISA shows v_add v1, v1, v1).
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // rows 0<->1, 2<->3
+    v = op(__uint_as_float(a.x), __uint_as_float(a.y));
+    const u32x2 c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // halves
+    return op(__uint_as_float(c.x), __uint_as_float(c.y));
+}
+
+// ---------------------------------------------------------------------------------------------
 // attention core: one workgroup per (image|text, head); head dim 64; T <= 16*NT (NT even)
 //   S^T = K.Q^T (keys on the MFMA row axis, so the softmax reduction over keys is mostly in-lane
 //   and the bf16 P tile is already the B operand of the P.V product), softmax fp32, O^T = V^T.P^T.
@@ -286,10 +317,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
                                                         int d, float scale)
 {
     constexpr int TPAD = NT * 16;
-    constexpr int VSTR = TPAD * 2 + 8;  // bytes per V^T row (+8 breaks the power-of-two stride)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *Ks = smem;                    // [TPAD][64] bf16, 16-B chunks XOR-swizzled by (row & 7)
-    char *Vt = smem + TPAD * 128;       // [64][VSTR]  V transposed: row = head dim, col = key
+    char *Vs = smem + TPAD * 128;       // same image for V; read column-wise with ds_read_b64_tr_b16
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = blockIdx.x, b = blockIdx.y;
@@ -304,16 +334,13 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             vv = *reinterpret_cast<const uint4 *>(base + (size_t)row * ld + 2 * d + c * 8);
         }
         *reinterpret_cast<uint4 *>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kk;
-        const uint32_t w[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const bf16_t val = (bf16_t)((w[e >> 1] >> ((e & 1) * 16)) & 0xffffu);
-            *reinterpret_cast<bf16_t *>(Vt + (c * 8 + e) * VSTR + row * 2) = val;
-        }
+        *reinterpret_cast<uint4 *>(Vs + row * 128 + ((c ^ (row & 7)) << 4)) = vv;
     }
     __syncthreads();
 
     const int fr = lane & 15, fg = lane >> 4;
+    const int tq = fr >> 2, tp = fr & 3, trow = 4 * fg + tq;   // transposed-read address roles (see lds_read_tr16)
+    const float c2 = scale * 1.44269504088896341f;            // softmax in the exp2 domain: exp2(s*c2 - max*c2)
     const int nqb = (T + 15) / 16;
     for (int qb = wave; qb < nqb; qb += 4) {
         const int qi = qb * 16 + fr;  // this lane's query (column of S^T)
@@ -335,6 +362,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             }
             sc[jt] = a;
         }
+        // V fragments, issued before the softmax so their latency hides under it:
+        // k-slot (fg, jj) of k-step s2 <-> key 16*(2*s2 + (jj>>2)) + 4*fg + (jj&3)
+        u32x2_t vraw[NT / 2][4][2];
+#pragma unroll
+        for (int s2 = 0; s2 < NT / 2; ++s2)
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const int r0 = 32 * s2 + trow;
+                const int ch = ((dt * 2 + (tp >> 1)) ^ (trow & 7)) << 4;
+                vraw[s2][dt][0] = lds_read_tr16(Vs + r0 * 128 + ch + 8 * (tp & 1));
+                vraw[s2][dt][1] = lds_read_tr16(Vs + (r0 + 16) * 128 + ch + 8 * (tp & 1));
+            }
         // sc[jt][r] = S[query qi][key jt*16 + 4*fg + r]
         float mx = -INFINITY;
 #pragma unroll
@@ -342,27 +381,31 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = jt * 16 + fg * 4 + r;
-                float v = sc[jt][r] * scale;
-                if (key >= T || (CAUSAL && key > qi)) v = -INFINITY;
-                sc[jt][r] = v;
-                mx = fmaxf(mx, v);
+                if (key >= T || (CAUSAL && key > qi)) sc[jt][r] = -INFINITY;
+                mx = fmaxf(mx, sc[jt][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = quad_rows_reduce(mx, [](float p, float q) { return fmaxf(p, q); });
+        const float m2 = mx == -INFINITY ? 0.f : mx * c2;      // scale > 0: max commutes with the scaling
         float sum = 0.f;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = __expf(sc[jt][r] - mx);
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[jt][r], c2, -m2));
                 sc[jt][r] = p;
                 sum += p;
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = quad_rows_reduce(sum, [](float p, float q) { return p + q; });
         const float inv = 1.f / sum;
 
-        // P (bf16) as the B operand: k-slot (fg, jj) of k-step s2 <-> key 16*(2*s2 + (jj>>2)) + 4*fg + (jj&3)
+        // the transposed reads are invisible to the compiler's counters: wait, then re-define the raw registers here so
+        // no copy into the MFMA operand tuples can be scheduled before the data has landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int s2 = 0; s2 < NT / 2; ++s2)
+            asm volatile("" : "+v"(vraw[s2][0][0]), "+v"(vraw[s2][0][1]), "+v"(vraw[s2][1][0]), "+v"(vraw[s2][1][1]),
+                              "+v"(vraw[s2][2][0]), "+v"(vraw[s2][2][1]), "+v"(vraw[s2][3][0]), "+v"(vraw[s2][3][1]));
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 oacc[4];
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -375,11 +418,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
             pf.u[3] = pack_bf16x2(sc[2 * s2 + 1][2] * inv, sc[2 * s2 + 1][3] * inv);
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const char *vr = Vt + (dt * 16 + fr) * VSTR + (32 * s2 + 4 * fg) * 2;
-                union { bf16x8 v; uint2 h[2]; } vf;
-                vf.h[0] = *reinterpret_cast<const uint2 *>(vr);
-                vf.h[1] = *reinterpret_cast<const uint2 *>(vr + 32);
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf.v, oacc[dt], 0, 0, 0);
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vraw[s2][dt][0], vraw[s2][dt][1], 0, 1, 2, 3));
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf.v, oacc[dt], 0, 0, 0);
             }
         }
         // oacc[dt][r] = O[query qi][dim dt*16 + 4*fg + r]
@@ -414,35 +454,10 @@ constexpr int AKB = 64;                       // keys per block
 constexpr int AIMG = AKB * 128;               // one [64 keys][64 dims] bf16 image
 constexpr int ABUF = 2 * AIMG;                // one buffer: K image + V image
 
-// 4 keys x 16 dims transposed read: each lane gets 4 consecutive keys of one dim (see header)
-typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));   // native vector types: asm operands stay in registers
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u32x2_t lds_read_tr16(const char *addr) {
-    u32x2_t v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)addr) : "memory");
-    return v;
-}
 
 // QB = 16-query blocks per wave (1 or 2).  With QB = 2 every K row fragment and every transposed V read feeds two
 // MFMAs, which halves the LDS bytes per FLOP -- the limiter at QB = 1, where each wave re-reads the whole 16 KiB
 // K/V block for 16 queries -- at the price of 128-query workgroups (more padding when T mod 128 is small).
-// reduce over the 4 lanes that share a query (lane, lane^16, lane^32, lane^48) with gfx950's row swaps (plain VALU;
-// __shfl_xor would go through ds_bpermute and the LDS crossbar's latency)
-template <typename F>
-__device__ __forceinline__ float quad_rows_reduce(float v, F op) {
-#ifdef MMR_ATTN_SHFL
-    v = op(v, __shfl_xor(v, 16, 64));
-    return op(v, __shfl_xor(v, 32, 64));
-#endif
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    // NB: read the two results as .x/.y through __uint_as_float.  __builtin_bit_cast(float, a[1]) on the returned
-    // ext-vector is miscompiled by ROCm 7.2 clang (element 0 is used for both: the ISA shows v_add v1, v1, v1).
-    const u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // rows 0<->1, 2<->3
-    v = op(__uint_as_float(a.x), __uint_as_float(a.y));
-    const u32x2 c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // halves
-    return op(__uint_as_float(c.x), __uint_as_float(c.y));
-}
-
 template <bool CAUSAL, int QB>
 __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
                                                                int T, int d, float scale)
@@ -745,7 +760,7 @@ static int launch_attention_t(const bf16_t *qkv, bf16_t *o, int Bn, int T, int h
 {
     ProfScope prof(MMR_PROF_ATTENTION, st);
     constexpr int TPAD = NT * 16;
-    constexpr int lds = TPAD * 128 + 64 * (TPAD * 2 + 8);
+    constexpr int lds = 2 * TPAD * 128;          // K image + V image
     static bool attr_set = false;
     if (!attr_set) {
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<NT, CAUSAL>),
