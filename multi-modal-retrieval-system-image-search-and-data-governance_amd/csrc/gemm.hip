@@ -538,11 +538,10 @@ template <int EPI, int NIW>
 static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
                           const GemmAux &aux, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    if (once.first()) {
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<EPI, NIW>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS + BM2 * 8));
-        attr_set = true;
     }
     // panels per tile-order group: the concurrent set of one XCD (32 CUs) should be near-square, at most 6 columns wide
     static const int force_pg = getenv("MMR_GEMM_PG") ? atoi(getenv("MMR_GEMM_PG")) : 0;
@@ -560,11 +559,10 @@ static int launch_gemm128(const bf16_t *A, const bf16_t *W, int M, int N, int K,
                           const GemmAux &aux, hipStream_t st)
 {
     const int lds = 2 * STAGE_BYTES + BM * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    if (once.first()) {
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
     }
     hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((M / BM) * (N / BN)), dim3(GEMM_THREADS), lds, st, A, W, M, N, K, bias, out,
                        aux);

@@ -1,6 +1,7 @@
 // Shared host/device helpers for the gfx950 kernels.  CDNA4 only: wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 
@@ -107,6 +108,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // ------------------------------------------------------------------ host side
 void set_error(const char *fmt, ...);
+
+// Per-kernel "attributes already set on this device" flag.  hipFuncSetAttribute applies to the current device only,
+// so the flag is kept per device (a process normally drives one GPU, but nothing here assumes it).
+struct DeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    bool first() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;   // unknown: just set it again
+        const unsigned long long bit = 1ull << dev;
+        return (mask.fetch_or(bit, std::memory_order_relaxed) & bit) == 0;
+    }
+};
 
 // Optional launch profiler (api_common.cpp): a ProfScope at a launch site records a HIP event pair
 // on the launch stream when mmr_prof_enable(1, n) is in force, and costs one branch otherwise.

@@ -1047,11 +1047,10 @@ static int launch_scan(const bf16_t *q, const bf16_t *gal, int Qc, int64_t N, co
     ProfScope prof(MMR_PROF_SCAN, st);
     using C = ScanCfg<E>;
     const int lds = SCAN_NBUF * C::TILE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    if (once.first()) {
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_kernel<E>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
     }
     const int qwaves = qpad / 32;
     hipLaunchKernelGGL(scan_kernel<E>, dim3(p.ntasks), dim3(C::SCAN_THREADS), lds, st, q, gal, Qc, N, p.ntiles, p.tpt,
@@ -1067,11 +1066,10 @@ static int launch_scan_f32(const float *q, const float *gal, int Qc, int64_t N, 
     ProfScope prof(MMR_PROF_SCAN, st);
     using C = ScanF32Cfg<E>;
     const int lds = SCAN_NBUF * C::TILE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    if (once.first()) {
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_f32_kernel<E>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
     }
     hipLaunchKernelGGL(scan_f32_kernel<E>, dim3(p.ntasks), dim3(C::SCAN_THREADS), lds, st, q, gal, Qc, N, p.ntiles, p.tpt,
                        qpad / 16, qpad, bmax, tmax);

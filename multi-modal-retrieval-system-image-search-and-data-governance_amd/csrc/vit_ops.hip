@@ -761,11 +761,10 @@ static int launch_attention_t(const bf16_t *qkv, bf16_t *o, int Bn, int T, int h
     ProfScope prof(MMR_PROF_ATTENTION, st);
     constexpr int TPAD = NT * 16;
     constexpr int lds = 2 * TPAD * 128;          // K image + V image
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    if (once.first()) {
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<NT, CAUSAL>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
     }
     hipLaunchKernelGGL((attention_kernel<NT, CAUSAL>), dim3(heads, Bn), dim3(256), lds, st, qkv, o, T, d, 0.125f);
     MMR_CHECK_LAUNCH();

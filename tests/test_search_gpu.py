@@ -257,3 +257,28 @@ def test_selection_paths_for_many_tasks(device):
     env = dict(__import__("os").environ, MMR_SEARCH_TPT="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_sharded_index_over_rccl(S, oracle, device):
+    """ShardedGalleryIndex through the real collective backend ("nccl" = RCCL) on this GPU: a one-rank group exercises
+    the all-gather + merge code path the multi-GPU bench takes (more ranks on one card are refused by RCCL; the
+    world_size-2 case runs over gloo in tests/test_host_logic.py)."""
+    import socket
+
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        gal = synth.synth_unit_rows(20000, 512, seed=31).bfloat16()
+        q = synth.synth_unit_rows(16, 512, seed=32).bfloat16()
+        index = S.ShardedGalleryIndex(gal.to(device))
+        score, idx = index.search(q.to(device), 10, 100.0)
+        oi, os_, _ = oracle.cosine_topk(q, gal, 10, 100.0)
+        assert idx.dtype == torch.int64
+        assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(score.cpu().numpy(), os_)
+    finally:
+        dist.destroy_process_group()
