@@ -18,6 +18,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
          "-Wno-unused-result", "-Wno-unused-value"] + os.environ.get("MMR_EXTRA_HIPCC_FLAGS", "").split()
 
 
+# per-source flags.  vit_ops.hip: keep MFMA results in arch VGPRs -- the attention kernels post-process every
+# accumulator with VALU code, and the default AGPR form costs a v_accvgpr_read/write per element (measured: streaming
+# attention 502 -> 463 us at ViT-L/14@336 B=128).  The GEMM and scan kernels already compile AGPR-free.
+PER_SOURCE_FLAGS = {"vit_ops.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+
+
 def _obj(src):
     return os.path.join(HERE, "_obj", os.path.splitext(src)[0] + ".o")
 
@@ -38,7 +44,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     def compile_one(src):
         sp, op = os.path.join(HERE, src), _obj(src)
         if force or _stale(op, [sp] + headers):
-            cmd = [HIPCC] + FLAGS + ["-c", sp, "-o", op]
+            cmd = [HIPCC] + FLAGS + PER_SOURCE_FLAGS.get(src, []) + ["-c", sp, "-o", op]
             if verbose:
                 print("[mmr build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -20,8 +20,13 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(bf16_t, b);
 }
+// two floats -> one dword of two bf16 (lo in bits 0..15): the vector cast lowers to ONE v_cvt_pk_bf16_f32; converting
+// the halves separately and OR-ing them costs three VALU instructions per pair
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    typedef __bf16 bf16x2_v __attribute__((ext_vector_type(2)));
+    typedef float f32x2_v __attribute__((ext_vector_type(2)));
+    const f32x2_v f = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_v));
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
