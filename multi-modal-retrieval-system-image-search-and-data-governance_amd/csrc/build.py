@@ -21,7 +21,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
 # per-source flags.  vit_ops.hip: keep MFMA results in arch VGPRs -- the attention kernels post-process every
 # accumulator with VALU code, and the default AGPR form costs a v_accvgpr_read/write per element (measured: streaming
 # attention 502 -> 463 us at ViT-L/14@336 B=128).  The GEMM and scan kernels already compile AGPR-free.
-PER_SOURCE_FLAGS = {"vit_ops.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# -fno-honor-nans drops the canonicalising v_max x,x clang puts in front of every fmaxf on an MFMA result (30 of the
+# 56 max instructions in the streaming-attention loop: 455 -> 440 us); nothing in that file tests for NaN.
+PER_SOURCE_FLAGS = {"vit_ops.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-honor-nans"]}
 
 
 def _obj(src):
