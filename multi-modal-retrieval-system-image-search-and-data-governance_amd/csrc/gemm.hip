@@ -230,6 +230,14 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
         }
     } else {
         char *my = smem + wave * 16384;          // [64 rows][16 chunks of 4 floats], chunk ^ (row & 15)
+        const int rc = lane & 15, rr0 = lane >> 4;
+        auto row_ptr = [&](int i) { return reinterpret_cast<float4 *>((float *)out + (row_base + i * 4 + rr0) * N + col_base + rc * 4); };
+        // residual rows first: 16 independent loads in flight while the tile goes through LDS (see the 256-row kernel)
+        float4 hv[16];
+        if constexpr (epi_resid(EPI)) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) hv[i] = *row_ptr(i);
+        }
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) {
             float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -243,18 +251,13 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
                     make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
             }
         }
-        const int rc = lane & 15, rr0 = lane >> 4;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int row = i * 4 + rr0;
             float4 v = *reinterpret_cast<const float4 *>(my + row * 256 + ((rc ^ (row & 15)) << 4));
             const size_t grow = row_base + row;
-            float4 *dst = reinterpret_cast<float4 *>((float *)out + grow * N + col_base + rc * 4);
-            if constexpr (epi_resid(EPI)) {
-                const float4 h = *dst;
-                v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
-            }
-            epi_store16(dst, v);
+            if constexpr (epi_resid(EPI)) { v.x += hv[i].x; v.y += hv[i].y; v.z += hv[i].z; v.w += hv[i].w; }
+            epi_store16(row_ptr(i), v);
             if constexpr (EPI == EPI_RESID_STATS_F32) {
                 uint2 pk;
                 pk.x = pack_bf16x2(v.x, v.y);
@@ -355,6 +358,13 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
 
     const int fr = lane & 15, fg = lane >> 4;
     const int w_row0 = wc * WCOLS;                // this wave's rows inside the contiguous W tile image
+    // the epilogue's bias values, fetched now so their latency hides under the whole main loop
+    float4 bias4[NIW];
+#pragma unroll
+    for (int ni = 0; ni < NIW; ++ni) {
+        bias4[ni] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if constexpr (epi_bias(EPI)) bias4[ni] = *reinterpret_cast<const float4 *>(bias + n0 + wc * WCOLS + ni * 16 + fg * 4);
+    }
 
     // prologue: stream elements 0..5 = W0,W1,A0,A1 of tile 0 and W0,W1 of tile 1
     float2 *row_stats = reinterpret_cast<float2 *>(smem + GEMM2_LDS);   // LNFOLD only: (mean, rstd) of the BM2 tile rows
@@ -456,7 +466,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         }
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) {
-            const float4 b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
+            const float4 b4 = bias4[ni];
             float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (epi_lnfold(EPI)) c4 = *reinterpret_cast<const float4 *>(aux.colsum + col_base + ni * 16 + fg * 4);
             const int c = ni * 2 + (fg >> 1);
@@ -478,32 +488,46 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         }
         const int rc = lane & 7, rr0 = lane >> 3;
         if (rc < 2 * NIW) {
+            uint4 rows16[16];                 // all row reads first (the accumulators are dead): one LDS latency, not 8
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = i * 8 + rr0;
-                const uint4 v = *reinterpret_cast<const uint4 *>(my + row * 128 + ((rc ^ (row & 7)) << 4));
-                epi_store16((bf16_t *)out + MMR_OUT_ROW(row_base + row) * N + col_base + rc * 8, v);
+                rows16[i] = *reinterpret_cast<const uint4 *>(my + row * 128 + ((rc ^ (row & 7)) << 4));
             }
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                epi_store16((bf16_t *)out + MMR_OUT_ROW(row_base + i * 8 + rr0) * N + col_base + rc * 8, rows16[i]);
         }
     } else {
-        // fp32: two passes of 64 rows; image [64 rows][16 chunks of 4 floats], chunk index XOR (row & 15)
+        // fp32: two passes of 64 rows; image [64 rows][16 chunks of 4 floats], chunk index XOR (row & 15).
+        // Residual epilogues read h before adding into it.  All 16 row segments of a pass are loaded up front
+        // (pass 1's before pass 0's stores: CDNA4 counts stores in vmcnt, in order), so the wave pays one
+        // load latency per pass instead of a load -> wait -> add -> store round trip per row.
         const int rc = lane & 15, rr0 = lane >> 4;
         const bool live = rc < 4 * NIW;
+        auto row_ptr = [&](int mh, int i) {
+            return reinterpret_cast<float4 *>((float *)out + (row_base + mh * 64 + i * 4 + rr0) * N + col_base + rc * 4);
+        };
+        auto load_resid = [&](int mh, float4 (&hv)[16]) {
+            if constexpr (epi_resid(EPI)) {
 #pragma unroll
-        for (int mh = 0; mh < 2; ++mh) {
+                for (int i = 0; i < 16; ++i) hv[i] = live ? *row_ptr(mh, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto to_lds = [&](int mh) {
 #pragma unroll
             for (int ni = 0; ni < NIW; ++ni) {
-                float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if constexpr (epi_bias(EPI)) b4 = *reinterpret_cast<const float4 *>(bias + col_base + ni * 16 + fg * 4);
                 const int c = ni * 4 + fg;
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi) {
                     const f32x4 a = acc[ni][mh * 4 + mi];
                     const int row = mi * 16 + fr;
                     *reinterpret_cast<float4 *>(my + row * 256 + ((c ^ (row & 15)) << 4)) =
-                        make_float4(a[0] + b4.x, a[1] + b4.y, a[2] + b4.z, a[3] + b4.w);
+                        make_float4(a[0] + bias4[ni].x, a[1] + bias4[ni].y, a[2] + bias4[ni].z, a[3] + bias4[ni].w);
                 }
             }
+        };
+        auto store_rows = [&](int mh, const float4 (&hv)[16]) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int row = i * 4 + rr0;
@@ -511,12 +535,8 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
                 const size_t grow = row_base + mh * 64 + row;
                 if (live) {
                     v = *reinterpret_cast<const float4 *>(my + row * 256 + ((rc ^ (row & 15)) << 4));
-                    float4 *dst = reinterpret_cast<float4 *>((float *)out + grow * N + col_base + rc * 4);
-                    if constexpr (epi_resid(EPI)) {
-                        const float4 h = *dst;
-                        v.x += h.x; v.y += h.y; v.z += h.z; v.w += h.w;
-                    }
-                    epi_store16(dst, v);
+                    if constexpr (epi_resid(EPI)) { v.x += hv[i].x; v.y += hv[i].y; v.z += hv[i].z; v.w += hv[i].w; }
+                    epi_store16(row_ptr(mh, i), v);
                 }
                 if constexpr (EPI == EPI_RESID_STATS_F32) {
                     if (live) {
@@ -530,7 +550,15 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
                     if (rc == 0) emit_row_partial(aux.stats_out, grow, col_base / WCOLS, N / WCOLS, s1, s2);
                 }
             }
-        }
+        };
+        float4 hv0[16], hv1[16];
+        load_resid(0, hv0);
+        to_lds(0);
+        if constexpr (NIW == 3) load_resid(1, hv1);   // 24 accumulators: room for both passes' rows at once
+        store_rows(0, hv0);
+        if constexpr (NIW == 4) load_resid(1, hv1);   // 32 accumulators: the second batch has to wait for registers
+        to_lds(1);
+        store_rows(1, hv1);
     }
 }
 
