@@ -326,6 +326,21 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
     const size_t ld = (size_t)3 * d;
     const bf16_t *base = qkv + (size_t)b * T * ld + hd * 64;
 
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nqb = (T + 15) / 16;
+    // Q fragments of this wave's first query block: issued together with the K/V loads, so the workgroup pays one
+    // global-load latency, not two (K/V -> barrier -> Q)
+    auto load_q = [&](int qb, bf16x8 (&qf)[2]) {
+        const int qi = qb * 16 + fr;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qf[s] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            if (qb < nqb && qi < T) qf[s] = *reinterpret_cast<const bf16x8 *>(base + (size_t)qi * ld + s * 32 + fg * 8);
+        }
+    };
+    bf16x8 qf[2];
+    load_q(wave, qf);
+
     for (int i = tid; i < TPAD * 8; i += 256) {
         const int row = i >> 3, c = i & 7;
         uint4 kk = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
@@ -338,18 +353,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
     }
     __syncthreads();
 
-    const int fr = lane & 15, fg = lane >> 4;
     const int tq = fr >> 2, tp = fr & 3, trow = 4 * fg + tq;   // transposed-read address roles (see lds_read_tr16)
     const float c2 = scale * 1.44269504088896341f;            // softmax in the exp2 domain: exp2(s*c2 - max*c2)
-    const int nqb = (T + 15) / 16;
     for (int qb = wave; qb < nqb; qb += 4) {
         const int qi = qb * 16 + fr;  // this lane's query (column of S^T)
-        bf16x8 qf[2];
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            qf[s] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (qi < T) qf[s] = *reinterpret_cast<const bf16x8 *>(base + (size_t)qi * ld + s * 32 + fg * 8);
-        }
+        if (qb != wave) load_q(qb, qf);
         f32x4 sc[NT];
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
