@@ -60,6 +60,17 @@ __global__ __launch_bounds__(256) void im2col_kernel(const TIN *__restrict__ px,
 // ---------------------------------------------------------------------------------------------
 // row LayerNorm helpers: one wave per row, VPL = d/64 values per lane held in registers
 // ---------------------------------------------------------------------------------------------
+// wave-wide sum in plain VALU: DPP inside each row of 16 lanes, then gfx950's row swaps across the four rows.
+// (__shfl_xor lowers to ds_bpermute: six dependent LDS-crossbar round trips per reduction.)
+__device__ __forceinline__ float wave_sum_valu(float v) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    v = row16_sum(v);
+    const u32x2 a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a.x) + __uint_as_float(a.y);           // .x/.y + __uint_as_float: see quad_rows_reduce
+    const u32x2 c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(c.x) + __uint_as_float(c.y);
+}
+
 template <int VPL>
 __device__ __forceinline__ void ln_row(float (&x)[VPL], const float *__restrict__ w, const float *__restrict__ b,
                                        int lane, int d, float eps)
@@ -67,11 +78,11 @@ __device__ __forceinline__ void ln_row(float (&x)[VPL], const float *__restrict_
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) s += x[j];
-    const float mean = wave_sum(s) / (float)d;
+    const float mean = wave_sum_valu(s) / (float)d;
     float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) { const float t = x[j] - mean; ss += t * t; }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)d + eps);
+    const float rstd = rsqrtf(wave_sum_valu(ss) / (float)d + eps);
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         const int col = j * 64 + lane;
@@ -92,8 +103,8 @@ __device__ __forceinline__ void emit_fold_inputs(const float (&x)[VPL], int lane
         ss += x[j] * x[j];
         xb[(size_t)row * d + j * 64 + lane] = f32_to_bf16(x[j]);
     }
-    s = wave_sum(s);
-    ss = wave_sum(ss);
+    s = wave_sum_valu(s);
+    ss = wave_sum_valu(ss);
     if (lane < LNFOLD_NP) stats[(size_t)row * LNFOLD_NP + lane] = lane == 0 ? make_float2(s, ss) : make_float2(0.f, 0.f);
 }
 
