@@ -9,7 +9,7 @@ N, E = int(os.environ.get("N", 1_000_000)), int(os.environ.get("E", 512))
 g = torch.randn(N, E, device=dev)
 g = (g / g.norm(dim=-1, keepdim=True)).bfloat16()
 idx = search.GalleryIndex(g)
-for Q in (1, 32, 64, 128, 256, 1024):
+for Q in [int(x) for x in os.environ.get("QS", "1,32,64,128,256,1024").split(",")]:
     q = torch.randn(Q, E, device=dev)
     q = (q / q.norm(dim=-1, keepdim=True)).bfloat16()
     for _ in range(3):
