@@ -33,6 +33,9 @@ constexpr int TILE_ROWS = 32;
 #define MMR_SCAN_NBUF 3
 #endif
 constexpr int SCAN_NBUF = MMR_SCAN_NBUF;
+#ifndef MMR_SCAN_CHAINS_FOR
+#define MMR_SCAN_CHAINS_FOR(waves) ((waves) == 4 ? 2 : 1)   // independent MFMA accumulation chains per wave
+#endif
 static_assert(SCAN_NBUF == 3 || SCAN_NBUF == 4, "wait counts below assume a prefetch distance of 2 or 3 tiles");
 constexpr int MAX_TPT = 64;                 // tiles per task
 constexpr int KS_MAX = 32;                  // candidate tiles kept per query
@@ -139,9 +142,12 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
 
         if (compute) {
             const char *tb = smem + cur * C::TILE_BYTES + rowoff;
-            f32x16 acc;
+            // CHAINS = 2 (one wave per SIMD, E = 768): even and odd k-steps accumulate into separate registers, so a
+            // wave that has no SIMD partner to alternate with is not held to one dependent MFMA at a time
+            constexpr int CHAINS = MMR_SCAN_CHAINS_FOR(C::SCAN_WAVES);
+            f32x16 acc, acc2;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+            for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
             // A fragments run PF k-steps ahead of the MFMA that consumes them.  hipcc waits lgkmcnt(0) in
             // front of every second MFMA when it schedules these reads itself (each wait then exposes the
             // LDS latency and the MFMA pipe idles half the time), so the reads are issued as inline asm and
@@ -172,13 +178,19 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
                 else if (younger == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[s % PF]));
                 else if (younger == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[s % PF]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[s % PF]));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % PF], bq[s], acc, 0, 0, 0);
+                const bool second = CHAINS == 2 && (s & 1);
+                if (second) acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % PF], bq[s], acc2, 0, 0, 0);
+                else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s % PF], bq[s], acc, 0, 0, 0);
                 if (s + PF < C::KSTEPS) {
                     // the MFMA above must have READ a[s % PF] before the next load overwrites it: the
                     // empty statement ties the accumulator to this point so the load cannot move above it
-                    asm volatile("" : "+v"(acc));
+                    if (second) asm volatile("" : "+v"(acc2)); else asm volatile("" : "+v"(acc));
                     issue(s + PF, a[s % PF]);
                 }
+            }
+            if (CHAINS == 2) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
             }
             // acc[i] = dot(query c, tile row (i&3) + 8*(i>>2) + 4*h)
             float m = -INFINITY;
