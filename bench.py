@@ -209,8 +209,10 @@ def main():
         scan_bytes = GALLERY_ROWS * EMBED * 2 + QUERIES * EMBED * 2 + QUERIES * TOPK * 8
         scan_gbs = scan_bytes * scan_n / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # newest round's PMC passes
+        tf = cands[-1] if cands else ""
+        if tf and os.path.exists(tf):
             try:
                 traffic = json.load(open(tf))
             except Exception:
