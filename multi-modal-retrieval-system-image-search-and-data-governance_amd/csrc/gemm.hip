@@ -4,13 +4,18 @@
 // layout of every projection in the CLIP towers (q/k/v, out_proj, fc1, fc2, patch-embed as GEMM,
 // visual/text projection).
 //
-// Structure: 128x128x64 tile, 256 threads = 2x2 waves, each wave a 64x64 sub-tile as 4x4
-// v_mfma_f32_16x16x32_bf16; operands staged by global_load_lds (16 B/lane) into a double-buffered,
-// XOR-swizzled LDS image (swizzle applied on the SOURCE address so the image stays lane-linear);
-// fragments read with conflict-free ds_read_b128.  The MFMA is issued with the weight fragment as
-// the "A" operand so each lane ends up with 4 CONSECUTIVE output columns of one row: epilogues are
-// 8-byte (bf16) / 16-byte (fp32) stores and the bias is one float4 load.
-// Fused epilogues: +bias -> bf16 | +bias, QuickGELU -> bf16 | +bias, += fp32 residual | plain fp32.
+// Two kernels (this file, top to bottom):
+//   gemm_bf16_kernel     128x128x64 tile, 256 threads = 2x2 waves of 64x64, two workgroups per CU: small batches, the
+//                        tiny test geometry, the final projection.
+//   gemm256_bf16_kernel  256x256x64 (or 256x192x64) tile, 512 threads = 2x4 waves of 128x64 (128x48), one workgroup
+//                        per CU, hand-pipelined: the kernel every large shape runs on (header further down).
+// Common to both: v_mfma_f32_16x16x32_bf16; operands staged by global_load_lds (16 B/lane) into an XOR-swizzled LDS
+// image (swizzle applied on the SOURCE address so the image stays lane-linear); fragments read with conflict-free
+// ds_read_b128.  The MFMA is issued with the weight fragment as the "A" operand so each lane ends up with 4
+// CONSECUTIVE output columns of one row; the epilogue transposes the wave's sub-tile through LDS and stores whole
+// row segments, 16 B per lane.
+// Fused epilogues (EPI_*): +bias -> bf16 | +bias, QuickGELU / exact GELU / tanh -> bf16 | +bias, += fp32 residual |
+// plain fp32 | +bias -> fp32 | LayerNorm-folded forms.
 #include "mmr_common.h"
 
 #include <stdlib.h>
@@ -42,7 +47,8 @@ __device__ __forceinline__ float epi_act(float v) {
     if constexpr (EPI == EPI_BIAS_GELU_BF16 || EPI == EPI_LNFOLD_GELU_BF16) {
         // QuickGELU x * sigmoid(1.702 x) (transformers/activations.py:117-123); hardware exp/rcp (1 ulp)
         // is far inside bf16 rounding.  Same formulation in both tile sizes.
-        return v * __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * v));
+        // exp(-1.702 v) as ONE multiply into exp2: -1.702 * log2(e) folded by hand (the compiler keeps two multiplies)
+        return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(v * -2.45546696f));
     } else if constexpr (EPI == EPI_BIAS_GELU_ERF_BF16) {
         // exact-GELU 0.5 x (1 + erf(x / sqrt 2)) (BERT "gelu").  erf by Abramowitz-Stegun 7.1.26 (|error| <=
         // 1.5e-7, far inside bf16 rounding) on the hardware exp/rcp: libm's erff cost 42 us on the fc1 shape.
