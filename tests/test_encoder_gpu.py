@@ -337,3 +337,40 @@ def test_baseline_config0_and_config2_end_to_end(device):
     v2, i2, d2 = mmr_amd.cosine_topk(tq, gallery, 10, return_dot64=True)
     oi2, _, od2 = search_ref.cosine_topk(tq.cpu(), gallery.cpu(), 10)
     assert np.array_equal(i2.cpu().numpy(), oi2) and np.array_equal(d2.cpu().numpy(), od2)
+
+
+@FOLD
+def test_outlier_channels_like_pretrained_residual_streams(L, device, fold):
+    """Pretrained CLIPs carry a few residual-stream channels that are orders of magnitude larger than the rest
+    (the seeded weights do not).  Plant such channels -- a huge class-token entry, a huge positional column, an
+    amplified fc2 output row in every layer -- and check the device path still tracks the fp32 oracle: the fp32
+    residual stream, fp32 LayerNorm statistics and bf16-only-at-the-GEMM-inputs design is what this exercises
+    (the LayerNorm-folded form feeds bf16(h) itself to the GEMM, so it is held to the same bound)."""
+    from oracle import clip_ref
+    ccfg = mmr_amd.get_config("tiny-test")
+    w = weights.make_clip_weights(ccfg, seed=11)
+    bf = lambda t: t.bfloat16().float()          # keep every tensor bf16-representable, like the generator does
+    w["v.cls"][7] = 48.0
+    w["v.pos"][:, 11] = bf(w["v.pos"][:, 11] + 24.0)
+    for i in range(ccfg.vision.layers):
+        w[f"v.l{i}.fc2.w"][13] = bf(w[f"v.l{i}.fc2.w"][13] * 16.0)
+        w[f"v.l{i}.fc2.b"][13] = 6.0
+    px = synth.synth_images(5, ccfg.vision.image_size, seed=12)
+    tower = _tower(ccfg, w, device, "v", fold)
+    B, T, d = px.shape[0], ccfg.vision.tokens, ccfg.vision.width
+    st = {}
+    with torch.no_grad():
+        feat_or = clip_ref.encode_image(w, ccfg.vision, px.bfloat16().float(), stages=st)
+    tap = torch.zeros(B * T, d, device=device)
+    feat = tower.forward(px.to(device), torch.float32, False, ccfg.vision.layers - 1, tap).cpu()
+    ref = st["layer1"]
+    assert ref.abs().max().item() > 20 * ref.abs().median().item()          # the outliers survived to the last layer
+    err = (tap.cpu().view(B, T, d) - ref).abs()
+    row_rms = ref.pow(2).mean(-1, keepdim=True).sqrt()
+    small = ref.abs() < 0.1 * ref.abs().amax(-1, keepdim=True)              # the ordinary channels of each row
+    print(f"fold={fold}: max err {err.max().item():.4f} of row max {ref.abs().max().item():.1f}; ordinary channels: "
+          f"max err/row rms {(err / row_rms)[small].max().item():.4f}; feature cos min {_cos(feat, feat_or).min().item():.6f}")
+    # bf16 GEMM inputs: errors scale with the row (2^-9 relative per operand), not with the element
+    assert err.max().item() <= 2e-2 * ref.abs().max().item()
+    assert (err / row_rms)[small].max().item() <= 5e-2                      # the outlier channel must not swamp the others
+    assert _cos(feat, feat_or).min().item() >= 1 - 1e-3
