@@ -248,3 +248,33 @@ def test_fold_ln_layout_adds_column_sums():
     bert = _lib.TowerCfg(kind=2, width=128, layers=2, heads=2, mlp=512, tokens=64, embed_dim=128, vocab=1000,
                          ln_eps=1e-12, fold_ln=1)
     assert L.mmr_tower_weights_bytes(ctypes.byref(bert)) == 0      # post-LN towers cannot fold
+
+
+def test_header_is_plain_c99_and_links_against_the_library(tmp_path):
+    """include/mmr.h is the drop-in boundary: it must compile as C (no C++/torch types) and a C program must link
+    against libmmr_hip.so using nothing but that header."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if not gcc:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "abi.c"
+    src.write_text('#include <stdio.h>\n#include "mmr.h"\n'
+                   'int main(void) {\n'
+                   '    mmr_tower_cfg c = {0};\n'
+                   '    c.kind = 0; c.width = 768; c.layers = 12; c.heads = 12; c.mlp = 3072; c.tokens = 50;\n'
+                   '    c.embed_dim = 512; c.image_size = 224; c.patch = 32; c.ln_eps = 1e-5f;\n'
+                   '    printf("%d %zu %zu\\n", mmr_version(), mmr_tower_weights_bytes(&c), mmr_search_workspace_bytes(1000000, 512, 256, 10));\n'
+                   '    return 0;\n}\n')
+    inc = os.path.join(root, "include")
+    subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(src)])
+    from mmr_amd import _lib
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    exe = tmp_path / "abi"
+    subprocess.check_call([gcc, "-std=c99", "-I", inc, str(src), "-o", str(exe), "-L", libdir, "-l:libmmr_hip.so",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    if out.returncode == 0:        # layout queries need no GPU; a box without the HIP runtime libraries may fail to start
+        ver, wbytes, ws = out.stdout.split()
+        assert int(ver) >= 1 and int(wbytes) > 170_000_000 and int(ws) > 0
