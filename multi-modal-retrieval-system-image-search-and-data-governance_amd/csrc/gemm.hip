@@ -302,7 +302,7 @@ constexpr int HALF_BYTES = 128 * BK * 2;            // 16 KiB: 128 rows x 64 bf1
 constexpr int STAGE2_BYTES = 4 * HALF_BYTES;        // A0 A1 W (up to 256 rows, contiguous image)
 constexpr int GEMM2_LDS = 2 * STAGE2_BYTES;         // 128 KiB
 
-template <int EPI, int NIW>
+template <int EPI, int NIW, bool PATCH = false>
 __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
     const float *__restrict__ bias, void *__restrict__ out, GemmAux aux, int pg)
@@ -338,6 +338,22 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     const int rr = lane >> 3;
     const int sc = (lane & 7) ^ rr;
     const bf16_t *a_src = A + (size_t)(m0 + wave * 16 + rr) * K + sc * 8;   // + half*128 rows, + 8 rows, + kt*64
+    // PATCH: the four A rows this lane stages per K-tile (half 0/1 x rows +0/+8) as pixel addresses.  K-tile kt covers
+    // channel kt/16, patch rows ky = 2*(kt%16) and +1; source chunk sc is kx = 8*(sc&3) .. +7 of row ky + (sc>>2)
+    // -- the same 16 contiguous bytes im2col would have copied.
+    const bf16_t *pa[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    if constexpr (PATCH) {
+        const int S = aux.pix_size, G = aux.pix_grid;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                int r = m0 + hh * 128 + wave * 16 + rr + 8 * j;
+                r = r < aux.patch_rows ? r : aux.patch_rows - 1;
+                const int gx = r % G, gy = (r / G) % G, b = r / (G * G);
+                pa[hh][j] = aux.pix + ((size_t)(b * 3) * S + gy * 32) * S + gx * 32 + (sc >> 2) * S + (sc & 3) * 8;
+            }
+    }
     const bf16_t *w_src = W + (size_t)(n0 + wave * 16 + rr) * K + sc * 8;
     const bf16_t *w1_src = W + (size_t)(n0 + 128 + wave * 8 + rr) * K + sc * 8;   // NIW == 3 only
     const int nkt = K / BK;
@@ -349,6 +365,12 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         char *dst = smem + (kt & 1) * STAGE2_BYTES + ((isA ? 0 : 2) + half) * HALF_BYTES;
         if (NIW == 3 && kind == 1) {
             glds16(w1_src + (size_t)kt * BK, dst + wave * 1024);
+            return;
+        }
+        if (PATCH && isA) {
+            const size_t off = (size_t)(kt >> 4) * aux.pix_size * aux.pix_size + (size_t)((kt & 15) * 2) * aux.pix_size;
+            glds16(pa[half][0] + off, dst + wave * 2048);
+            glds16(pa[half][1] + off, dst + wave * 2048 + 1024);
             return;
         }
         const bf16_t *src = (isA ? a_src : w_src) + (size_t)half * 128 * K + (size_t)kt * BK;
@@ -568,13 +590,13 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     }
 }
 
-template <int EPI, int NIW>
+template <int EPI, int NIW, bool PATCH = false>
 static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
                           const GemmAux &aux, hipStream_t st)
 {
     static DeviceOnce once;
     if (once.first()) {
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<EPI, NIW>),
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<EPI, NIW, PATCH>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS + BM2 * 8));
     }
     // panels per tile-order group: the concurrent set of one XCD (32 CUs) should be near-square, at most 6 columns wide
@@ -582,7 +604,7 @@ static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K,
     const int gn = N / (64 * NIW);
     const int cols = gn < 6 ? gn : 6;
     const int pg = force_pg > 0 ? force_pg : (32 + cols - 1) / cols;
-    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, NIW>), dim3((M / BM2) * gn), dim3(GEMM2_THREADS),
+    hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, NIW, PATCH>), dim3((M / BM2) * gn), dim3(GEMM2_THREADS),
                        GEMM2_LDS + BM2 * 8, st, A, W, M, N, K, bias, out, aux, pg);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
@@ -655,6 +677,23 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
     }
 #undef MMR_GEMM_CASE
     return MMR_EINVAL;
+}
+
+// Patch-embed conv as a GEMM with the patch gather fused into the A-tile loads (patch 32, bf16 pixels): out[M,N] fp32 =
+// patches(pix)[M,3072] . W[N,3072]^T, no im2col pass.  Returns MMR_ENOTSUP when the shape does not fit the 256-row
+// kernel (the caller then runs im2col + launch_gemm).
+int launch_gemm_patch32(const bf16_t *pix, int B, int S, const bf16_t *W, int M, int N, float *out, hipStream_t st)
+{
+    const int G = S / 32, K = 3 * 32 * 32;
+    if (S % 32 || B < 1 || M % BM2 || M < B * G * G) return MMR_ENOTSUP;
+    const long long t256 = N % 256 ? -1 : (long long)(M / BM2) * (N / 256), t192 = N % 192 ? -1 : (long long)(M / BM2) * (N / 192);
+    if (t256 < 128 && t192 < 128) return MMR_ENOTSUP;
+    GemmAux aux{};
+    aux.pix = pix; aux.pix_size = S; aux.pix_grid = G; aux.patch_rows = B * G * G;
+    ProfScope prof(MMR_PROF_GEMM, st);
+    const long long c256 = t256 >= 128 ? (t256 + 255) / 256 * 256 : -1, c192 = t192 >= 128 ? (t192 + 255) / 256 * 192 : -1;
+    if (c192 > 0 && (c256 < 0 || c192 < c256)) return launch_gemm256<EPI_STORE_F32, 3, true>(nullptr, W, M, N, K, nullptr, out, aux, st);
+    return launch_gemm256<EPI_STORE_F32, 4, true>(nullptr, W, M, N, K, nullptr, out, aux, st);
 }
 
 int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,

@@ -68,6 +68,11 @@ struct GemmAux {
     float2 *stats_out;       // RESID_STATS: [M][LNFOLD_NP] partials of the new residual rows
     bf16_t *xout;            // RESID_STATS: bf16 copy of the new residual rows
     float inv_d, eps;        // 1 / width, LayerNorm epsilon
+    // PATCH form of the 256-row kernel (patch-embed conv as GEMM, patch 32): A is not a matrix in memory but gathered
+    // from bf16 NCHW pixels: row = (image b, patch gy, gx), k = (channel, ky, kx)
+    const bf16_t *pix;       // [B,3,S,S]
+    int pix_size, pix_grid;  // S, G = S / 32
+    int patch_rows;          // B * G * G: rows past it (tile padding) re-read the last patch
 };
 
 __device__ __forceinline__ void emit_row_partial(float2 *stats, size_t row, int slab, int nslabs, float s, float ss)

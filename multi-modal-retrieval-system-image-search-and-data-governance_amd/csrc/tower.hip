@@ -15,6 +15,7 @@ enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_ST
        EPI_BIAS_F32 = 4, EPI_BIAS_GELU_ERF_BF16 = 5, EPI_BIAS_TANH_BF16 = 6, EPI_LNFOLD_BF16 = 7, EPI_LNFOLD_GELU_BF16 = 8,
        EPI_RESID_STATS_F32 = 9 };
 int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st);
+int launch_gemm_patch32(const bf16_t *pix, int B, int S, const bf16_t *W, int M, int N, float *out, hipStream_t st);
 int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, const GemmAux &aux, hipStream_t st);
 // vit_ops.hip
 int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P, int G, int K, int Kpad, hipStream_t st);
@@ -253,8 +254,15 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
     // ---- embeddings
     if (c.kind == 0) {
         const int G = c.image_size / c.patch, K = patch_k(c), Kp = patch_kpad(c);
-        if ((rc = launch_im2col(input, in_dtype, big, B, c.image_size, c.patch, G, K, Kp, st))) return rc;
-        if ((rc = launch_gemm(EPI_STORE_F32, big, t->g<bf16_t>(MMR_P_PATCH_W), p.Mp_pad, d, Kp, nullptr, pe, st))) return rc;
+        // patch 32 + bf16 pixels: the patch gather rides in the GEMM's A-tile loads (no im2col pass, no patch matrix)
+        rc = MMR_ENOTSUP;
+        if (c.patch == 32 && in_dtype == MMR_BF16 && K == Kp)
+            rc = launch_gemm_patch32((const bf16_t *)input, B, c.image_size, t->g<bf16_t>(MMR_P_PATCH_W), p.Mp_pad, d, pe, st);
+        if (rc == MMR_ENOTSUP) {
+            if ((rc = launch_im2col(input, in_dtype, big, B, c.image_size, c.patch, G, K, Kp, st))) return rc;
+            rc = launch_gemm(EPI_STORE_F32, big, t->g<bf16_t>(MMR_P_PATCH_W), p.Mp_pad, d, Kp, nullptr, pe, st);
+        }
+        if (rc) return rc;
         if ((rc = launch_embed_vision(pe, t->g<float>(MMR_P_CLS), t->g<float>(MMR_P_POS), t->g<float>(MMR_P_LN_PRE_W),
                                       t->g<float>(MMR_P_LN_PRE_B), h, B, T, d, c.ln_eps, xb, stats, st))) return rc;
     } else {

@@ -374,3 +374,19 @@ def test_outlier_channels_like_pretrained_residual_streams(L, device, fold):
     assert err.max().item() <= 2e-2 * ref.abs().max().item()
     assert (err / row_rms)[small].max().item() <= 5e-2                      # the outlier channel must not swamp the others
     assert _cos(feat, feat_or).min().item() >= 1 - 1e-3
+
+
+def test_bf16_pixels_fused_patch_gather_equals_im2col_path(device):
+    """bf16 pixels at patch 32 take the GEMM with the patch gather fused into its A-tile loads (no im2col pass); fp32
+    pixels holding the same values go through im2col + the plain GEMM.  Same operands, same kernel arithmetic:
+    the features must agree bit for bit, at the bench's batch (fused) and at a small one (falls back to im2col)."""
+    model, _ = mmr_amd.load("ViT-B/32", device=device)
+    px = synth.synth_images(256, 224, seed=21).bfloat16()
+    f_fused = model.encode_image(px.to(device))
+    f_plain = model.encode_image(px.float().to(device))
+    assert torch.isfinite(f_fused).all()
+    assert torch.equal(f_fused, f_plain)
+    assert torch.equal(model.encode_image(px[:5].to(device)), model.encode_image(px[:5].float().to(device)))
+    # ragged batch: 300 images are processed as one 300-image launch sequence (padding rows re-read the last patch)
+    px2 = synth.synth_images(300, 224, seed=22).bfloat16()
+    assert torch.equal(model.encode_image(px2.to(device)), model.encode_image(px2.float().to(device)))
