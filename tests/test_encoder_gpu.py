@@ -94,8 +94,13 @@ def test_layernorm(L, device, d):
     assert err <= 1e-2 * ref.abs().max().item(), err
 
 
+# sequence lengths around every kernel boundary: 16-key MFMA tiles, the 32/64/96-token in-register kernels, the 64-key
+# blocks and 64/128-query workgroups of the streaming kernel, and the largest supported length
 @pytest.mark.parametrize("T,causal", [(17, 0), (50, 0), (77, 1), (77, 0), (257, 0), (577, 0), (17, 1), (1, 0), (64, 1),
-                                      (97, 0), (130, 1), (608, 0)])
+                                      (97, 0), (130, 1), (608, 0), (2, 1), (15, 0), (16, 1), (31, 0), (32, 0), (33, 1),
+                                      (63, 0), (65, 0), (95, 1), (96, 0), (127, 0), (128, 1), (129, 0), (191, 1),
+                                      (192, 0), (193, 0), (255, 1), (256, 0), (320, 0), (383, 1), (384, 0), (385, 0),
+                                      (511, 0), (512, 1), (513, 0), (600, 1)])
 def test_attention_core(L, device, T, causal):
     B, heads = 3, 2
     d = heads * 64
