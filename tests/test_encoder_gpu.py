@@ -33,7 +33,10 @@ def _cos(a, b):
                                    (256, 256, 64), (512, 256, 128), (256, 768, 192), (4096, 1024, 256),
                                    (12800, 768, 768),       # 256x192 tiles (200 tiles beat 150 of 256x256)
                                    (8192, 768, 128),        # 256x192 tiles, exactly 128 of them
-                                   (12800, 1024, 128)])     # 256x256 tiles
+                                   (12800, 1024, 128),      # 256x256 tiles
+                                   (33024, 256, 64),        # 129 tiles: workgroup count not a multiple of the 8 XCDs
+                                   (11008, 768, 64),        # 43 row panels x 4: ragged last tile-order group
+                                   (35840, 512, 128)])      # 280 tiles, 2 per panel: more than one round
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_epilogues(L, device, M, N, K, epi):
     g = torch.Generator().manual_seed(M + N + K + epi)
