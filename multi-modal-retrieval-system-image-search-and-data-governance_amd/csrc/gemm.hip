@@ -91,10 +91,16 @@ __device__ __forceinline__ int tile_off(int row, int c) {
     return (row >> 3) * 1024 + (row & 7) * 128 + ((c ^ (row & 7)) << 4);
 }
 
-template <int EPI>
 #ifndef MMR_GEMM_MINWAVES
 #define MMR_GEMM_MINWAVES 1
 #endif
+// NSTG = LDS stages.  2: 64 KiB, two workgroups per CU (many tiles).  4: 128 KiB, one workgroup per CU, three K-tiles
+// in flight -- for grids that do not fill the chip anyway (small batches), where each K-iteration is otherwise one
+// exposed load latency: fc2 at M=512 ran 48 iterations x 0.8 us.
+template <int NSTG>
+struct Gemm128Cfg { static constexpr int LDS = NSTG * STAGE_BYTES + BM * 8; };
+
+template <int EPI, int NSTG>
 __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
     const float *__restrict__ bias, void *__restrict__ out, GemmAux aux)
@@ -140,19 +146,30 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
 
     const int fr = lane & 15, fg = lane >> 4;
     const int nkt = K / BK;
-    float2 *row_stats = reinterpret_cast<float2 *>(smem + 2 * STAGE_BYTES);   // LNFOLD only: (mean, rstd) of the BM tile rows
+    float2 *row_stats = reinterpret_cast<float2 *>(smem + NSTG * STAGE_BYTES);   // LNFOLD only: (mean, rstd) of the BM tile rows
+    auto prologue = [&]() {
+#pragma unroll
+        for (int s = 0; s < NSTG - 1; ++s)
+            if (s < nkt) stage(s, s);
+    };
     if constexpr (epi_lnfold(EPI)) {
         LnfoldLoads ld;
         lnfold_issue(aux, m0, ld);
-        stage(0, 0);
+        prologue();
         lnfold_finish(aux, ld, row_stats);
     } else {
-        stage(0, 0);
+        prologue();
     }
-    __syncthreads();
-    int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) stage(kt + 1, cur ^ 1);
+        // K-tile kt has landed once at most `younger` later stages (8 loads per wave each) are still in flight ...
+        const int younger = min(NSTG - 2, nkt - 1 - kt);
+        if (younger >= 2) wait_vmcnt<16>();
+        else if (younger == 1) wait_vmcnt<8>();
+        else wait_vmcnt<0>();
+        // ... for every wave after the barrier, which also says everyone is done reading K-tile kt-1's buffer:
+        __builtin_amdgcn_s_barrier();
+        if (kt + NSTG - 1 < nkt) stage(kt + NSTG - 1, (kt + NSTG - 1) % NSTG);   // into that buffer
+        const int cur = kt % NSTG;
         const char *ta = smem + cur * STAGE_BYTES;
         const char *tw = ta + TILE_A_BYTES;
 #pragma unroll
@@ -175,9 +192,8 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
             __builtin_amdgcn_s_setprio(0);
 #endif
         }
-        __syncthreads();  // drains the prefetch (vmcnt(0)) and fences the buffer swap
-        cur ^= 1;
     }
+    __syncthreads();      // the epilogue reuses the staging buffers
 
 #ifdef MMR_GEMM_NOEPI   // diagnostic build: time prologue + main loop only (outputs are wrong)
     {
@@ -610,20 +626,30 @@ static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K,
     return MMR_OK;
 }
 
+template <int EPI, int NSTG>
+static int launch_gemm128s(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
+                           const GemmAux &aux, hipStream_t st)
+{
+    constexpr int lds = Gemm128Cfg<NSTG>::LDS;
+    static DeviceOnce once;
+    if (once.first()) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI, NSTG>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    hipLaunchKernelGGL((gemm_bf16_kernel<EPI, NSTG>), dim3((M / BM) * (N / BN)), dim3(GEMM_THREADS), lds, st, A, W, M, N, K,
+                       bias, out, aux);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
 template <int EPI>
 static int launch_gemm128(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
                           const GemmAux &aux, hipStream_t st)
 {
-    const int lds = 2 * STAGE_BYTES + BM * 8;
-    static DeviceOnce once;
-    if (once.first()) {
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_bf16_kernel<EPI>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    }
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((M / BM) * (N / BN)), dim3(GEMM_THREADS), lds, st, A, W, M, N, K, bias, out,
-                       aux);
-    MMR_CHECK_LAUNCH();
-    return MMR_OK;
+    static const int force = getenv("MMR_GEMM128_STAGES") ? atoi(getenv("MMR_GEMM128_STAGES")) : 0;   // 2 / 4: A/B aid
+    const long long tiles = (long long)(M / BM) * (N / BN);
+    const bool deep = force ? force == 4 : tiles <= 256;      // one workgroup per CU anyway: spend the LDS on prefetch depth
+    return deep ? launch_gemm128s<EPI, 4>(A, W, M, N, K, bias, out, aux, st) : launch_gemm128s<EPI, 2>(A, W, M, N, K, bias, out, aux, st);
 }
 
 // host launcher (internal): shapes are validated by the caller in tower.hip
