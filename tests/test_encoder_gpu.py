@@ -36,7 +36,9 @@ def _cos(a, b):
                                    (12800, 1024, 128),      # 256x256 tiles
                                    (33024, 256, 64),        # 129 tiles: workgroup count not a multiple of the 8 XCDs
                                    (11008, 768, 64),        # 43 row panels x 4: ragged last tile-order group
-                                   (35840, 512, 128)])      # 280 tiles, 2 per panel: more than one round
+                                   (35840, 512, 128),       # 280 tiles, 2 per panel: more than one round
+                                   (2304, 384, 128), (3072, 768, 3072),     # 128x128 tiles (M > 2048, too few 256-row tiles)
+                                   (2048, 128, 64), (128, 3072, 768)])      # 128x32 tiles at both ends of their range
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6])
 def test_gemm_epilogues(L, device, M, N, K, epi):
     g = torch.Generator().manual_seed(M + N + K + epi)

@@ -6,7 +6,7 @@ import mmr_amd
 
 dev = torch.device("cuda:0")
 model, _ = mmr_amd.load("ViT-B/32", device=dev)
-for B in (1, 8, 32, 64):
+for B in [int(x) for x in os.environ.get("BS", "1,8,32,64").split(",")]:
     px = torch.randn(B, 3, 224, 224, device=dev)
     for _ in range(3):
         model.encode_image(px)
