@@ -804,7 +804,8 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
     auto cost = [&](int bn) -> long long {
         if (M % BM2 || N % bn) return -1;
         const long long tiles = (long long)(M / BM2) * (N / bn);
-        if (tiles < 128) return -1;
+        static const int min_tiles = getenv("MMR_GEMM_MINTILES") ? atoi(getenv("MMR_GEMM_MINTILES")) : 128;   // A/B aid
+        if (tiles < min_tiles) return -1;
         return (tiles + cus - 1) / cus * bn;
     };
     const long long c256 = cost(256), c192 = cost(192);
