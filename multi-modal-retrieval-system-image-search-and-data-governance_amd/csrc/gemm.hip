@@ -91,9 +91,6 @@ __device__ __forceinline__ int tile_off(int row, int c) {
     return (row >> 3) * 1024 + (row & 7) * 128 + ((c ^ (row & 7)) << 4);
 }
 
-#ifndef MMR_GEMM_MINWAVES
-#define MMR_GEMM_MINWAVES 1
-#endif
 // NSTG = LDS stages.  2: 64 KiB, two workgroups per CU (many tiles).  4: 128 KiB, one workgroup per CU, three K-tiles
 // in flight -- for grids that do not fill the chip anyway (small batches), where each K-iteration is otherwise one
 // exposed load latency: fc2 at M=512 ran 48 iterations x 0.8 us.
@@ -101,7 +98,7 @@ template <int NSTG>
 struct Gemm128Cfg { static constexpr int LDS = NSTG * STAGE_BYTES + BM * 8; };
 
 template <int EPI, int NSTG>
-__global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_kernel(
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bf16_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
     const float *__restrict__ bias, void *__restrict__ out, GemmAux aux)
 {
@@ -180,17 +177,11 @@ __global__ __launch_bounds__(GEMM_THREADS, MMR_GEMM_MINWAVES) void gemm_bf16_ker
                 af[i] = *reinterpret_cast<const bf16x8 *>(ta + tile_off(wm * 64 + i * 16 + fr, ks * 4 + fg));
                 wf[i] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(wn * 64 + i * 16 + fr, ks * 4 + fg));
             }
-#ifdef MMR_GEMM_SETPRIO
-            __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 4; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
-#ifdef MMR_GEMM_SETPRIO
-            __builtin_amdgcn_s_setprio(0);
-#endif
         }
     }
     __syncthreads();      // the epilogue reuses the staging buffers

@@ -34,11 +34,6 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
-}
 // Fixed-order fp64 butterfly: identical in every lane, and identical to oracle/search_ref.c.
 __device__ __forceinline__ double wave_sum_f64_butterfly(double v) {
 #pragma unroll
