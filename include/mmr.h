@@ -192,11 +192,11 @@ int mmr_preprocess_batch(const void *desc, int B, int S, int max_rows, float mea
  * class, recorded on the launch stream.  Off by default.
  * ---------------------------------------------------------------------------------------- */
 enum {
-    MMR_PROF_GEMM = 0,       /* gemm_bf16_kernel (all epilogues) */
-    MMR_PROF_ATTENTION = 1,  /* attention_kernel */
+    MMR_PROF_GEMM = 0,       /* the three GEMM kernels (256-row, 128x128, 128x32), all epilogues */
+    MMR_PROF_ATTENTION = 1,  /* attention_kernel / attention_stream_kernel */
     MMR_PROF_ROWWISE = 2,    /* LayerNorm / embedding / pooling / patch gather / output cast */
     MMR_PROF_SCAN = 3,       /* scan_kernel (gallery stream, HBM-bound) */
-    MMR_PROF_FINALIZE = 4,   /* finalize_kernel (selection + exact re-rank) */
+    MMR_PROF_FINALIZE = 4,   /* select / rescore / rank kernels (selection + exact re-rank) */
     MMR_PROF_EXACT = 5,      /* exhaustive exact kernels */
     MMR_PROF_CLASSES = 6
 };
