@@ -57,6 +57,9 @@ def _clip(name, image, patch, vw, vl, vmlp, tw, tl, tmlp, embed, ctx=77, vocab=4
 MODEL_CONFIGS = {
     # OpenAI CLIP ViT-B/32: the backbone every EN script in the reference loads.
     "ViT-B/32": _clip("ViT-B/32", 224, 32, 768, 12, 3072, 512, 12, 2048, 512),
+    # OpenAI CLIP ViT-B/16: not loaded by the reference's scripts, listed by `clip.available_models()`; same towers
+    # as B/32 with 14x14 patches per side (197 tokens -> the streaming attention kernel).
+    "ViT-B/16": _clip("ViT-B/16", 224, 16, 768, 12, 3072, 512, 12, 2048, 512),
     # openai/clip-vit-large-patch14 (HF), used by the CN pipeline's image tower.
     "ViT-L/14": _clip("ViT-L/14", 224, 14, 1024, 24, 4096, 768, 12, 3072, 768),
     "ViT-L/14@336px": _clip("ViT-L/14@336px", 336, 14, 1024, 24, 4096, 768, 12, 3072, 768),
@@ -104,6 +107,7 @@ def get_bert_config(name: str) -> BertTextConfig:
 # HF hub ids the reference passes to from_pretrained, mapped to the same geometry.
 MODEL_ALIASES = {
     "openai/clip-vit-base-patch32": "ViT-B/32",
+    "openai/clip-vit-base-patch16": "ViT-B/16",
     "openai/clip-vit-large-patch14": "ViT-L/14",
     "openai/clip-vit-large-patch14-336": "ViT-L/14@336px",
 }

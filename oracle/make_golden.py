@@ -187,6 +187,8 @@ def main():
         encoder_golden("tiny-test", 4, 3, with_stages=True)
     if a.only in ("", "b32"):
         encoder_golden("ViT-B/32", 4, 3, with_stages=False)
+    if a.only in ("", "b16"):
+        encoder_golden("ViT-B/16", 2, 2, with_stages=False)
     if not a.skip_large and a.only in ("", "l14"):
         encoder_golden("ViT-L/14", 1, 2, with_stages=False, with_text=True)
     if a.only in ("", "bert"):

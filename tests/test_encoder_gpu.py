@@ -182,7 +182,8 @@ def test_tiny_text_vs_golden_and_oracle(L, device, golden_dir, fold):
     assert _cos(feat, torch.from_numpy(g["text_features"])).min().item() >= 1 - 1e-3
 
 
-@pytest.mark.parametrize("name,fn", [("ViT-B/32", "encoder_ViT-B-32.npz"), ("ViT-L/14", "encoder_ViT-L-14.npz"),
+@pytest.mark.parametrize("name,fn", [("ViT-B/32", "encoder_ViT-B-32.npz"), ("ViT-B/16", "encoder_ViT-B-16.npz"),
+                                     ("ViT-L/14", "encoder_ViT-L-14.npz"),
                                      ("ViT-L/14@336px", "encoder_ViT-L-14_336px.npz")])
 @FOLD
 def test_full_models_vs_hf_golden(device, golden_dir, name, fn, fold):

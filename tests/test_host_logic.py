@@ -82,7 +82,7 @@ def test_tower_layout(lib):
 
 
 def test_configs_and_weights():
-    assert mmr_amd.available_models() == ["ViT-B/32", "ViT-L/14", "ViT-L/14@336px"]
+    assert mmr_amd.available_models() == ["ViT-B/32", "ViT-B/16", "ViT-L/14", "ViT-L/14@336px"]
     assert config.get_config("openai/clip-vit-large-patch14").name == "ViT-L/14"
     with pytest.raises(RuntimeError):
         config.get_config("RN50")

@@ -18,7 +18,8 @@ def _gold(golden_dir, name):
     return np.load(os.path.join(golden_dir, name))
 
 
-@pytest.mark.parametrize("name,fn", [("tiny-test", "encoder_tiny-test.npz"), ("ViT-B/32", "encoder_ViT-B-32.npz")])
+@pytest.mark.parametrize("name,fn", [("tiny-test", "encoder_tiny-test.npz"), ("ViT-B/32", "encoder_ViT-B-32.npz"),
+                                     ("ViT-B/16", "encoder_ViT-B-16.npz")])
 def test_encoder_oracle_matches_hf_golden(golden_dir, name, fn):
     g = _gold(golden_dir, fn)
     ccfg = mmr_amd.get_config(name)
