@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
-"""Benchmark of the hot path on MI355X: batched CLIP ViT-B/32 bf16 encode + cosine top-10 over a
-1M x 512 bf16 gallery (BASELINE.json configs[1]).
+"""Benchmark of the hot path on MI355X: batched CLIP encode + cosine top-10 over a gallery shard per GPU.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 20 --warmup 5                      # BASELINE.json configs[1] (default)
+    python bench.py --config cfg4                                       # one GPU's share of configs[3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W [--config cfgX]
 
-One STEP, per rank (inputs already resident in HBM):
-  encode leg : encode_image(256 synthetic 224x224x3 bf16 images) -> 256 L2-normalised bf16 features
-  search leg : top-10 of 256 (replicated, seeded) bf16 queries over this rank's 1M x 512 bf16 gallery
-               shard; for N > 1 one RCCL all-gather of the packed per-shard top-10 + exact merge.
-Weak scaling: per-rank work is fixed; at N ranks a step encodes N*256 images (data-parallel, no
-collective) and answers 256 queries over an N x 1M gallery.
-`value` = N*256 / step time = images/s through encode+search; the legs are reported separately
-(`encode_images_per_s`, `search_queries_per_s`, `search_gpairs_per_s`) from HIP events recorded on
-the launch stream inside the same timed region.
-`roofline` is for the kernel that dominates the step (the bf16 MFMA GEMM); `roofline_search` for the
-HBM-bound gallery scan; their launch durations come from HIP event pairs around every launch in a
-second pass over the same K steps (instrumenting the timed region itself would slow it ~15%).  `cpu_baseline` times the CPU oracle / the reference's own torch expression
-on the host cores of this box on a bounded sample (rank 0, N = 1 only).
+Workloads (--config; names follow SURVEY.md section 8d; per RANK, weak scaling -- fixed per-GPU work):
+  cfg2  BASELINE configs[1]: ViT-B/32 bf16 encode of 256 images + top-10 of 256 queries over 1M x 512 bf16 rows
+  cfg3  BASELINE configs[2]: CLIP text tower bf16 on 256 prompts, their features are the queries over 1M x 512 rows
+  cfg4  BASELINE configs[3]: search only, 1.25M x 512 rows per rank (8 ranks = the 10M gallery), 256 queries
+  cfg5  BASELINE configs[4]: ViT-L/14@336 bf16 encode of 128 images per rank + top-10 of 128 queries over 1M x 768 rows
+One STEP, per rank (inputs already resident in HBM): the config's encode leg (none for cfg4), then the search leg:
+local top-10 over this rank's shard; for N > 1 ONE RCCL all-gather (all_gather_into_tensor, async) of the packed
+per-shard top-10 and an exact merge.  With N > 1 the steps are software-pipelined: step i's all-gather is in
+flight while step i+1 encodes and scans, and every step's merge completes inside the timed region.
+`value` = units of the config (images, texts or queries) all ranks processed per second through the whole step;
+the legs are reported separately from HIP events recorded on the launch stream inside the timed region.
+`roofline` is for the kernel that dominates the step (the bf16 MFMA GEMM; the gallery scan for cfg4);
+`roofline_search` for the gallery scan, which at 256 resident queries is paced by HBM and MFMA alike -- both
+fractions are given.  Launch durations come from HIP event pairs around every launch in a second pass over the same
+K steps (instrumenting the timed region itself would slow it ~15%).  `search_sweep` (cfg2) times the search at
+Q = 1, 32, 256, 1024 queries.  After the timed region the last step's result is VERIFIED
+(`verify`): every returned global id is re-scored by the rank that owns it (fp64) and must equal the merged dot,
+the list must be sorted / unique, and the merged k-th dot must be >= every rank's local (k+1)-th -- together that
+is the proof that the sharded result is the exact global top-k.  `cpu_baseline` times the CPU oracle / the
+reference's own torch expression on the host cores of this box on a bounded sample (rank 0, N = 1, cfg2 only).
 """
 import argparse
 import json
@@ -31,25 +38,30 @@ sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 
-MODEL = "ViT-B/32"
-BATCH = 256
-GALLERY_ROWS = 1_000_000
-EMBED = 512
 TOPK = 10
-QUERIES = 256
 # dense peaks from /opt/skills/guides/MI355X_MICROARCH.md (spec): bf16 MFMA ~2.5 PFLOP/s, HBM3E 8 TB/s
 PEAK_BF16_TFLOPS = 2500.0
 PEAK_HBM_GBS = 8000.0
 
+CONFIGS = {
+    # name: (model, encode kind, batch per rank, gallery rows per rank, queries, BASELINE.json entry)
+    "cfg2": dict(model="ViT-B/32", encode="image", batch=256, rows=1_000_000, queries=256, baseline="configs[1]"),
+    "cfg3": dict(model="ViT-B/32", encode="text", batch=256, rows=1_000_000, queries=256, baseline="configs[2]"),
+    "cfg4": dict(model="ViT-B/32", encode="none", batch=0, rows=1_250_000, queries=256, baseline="configs[3]"),
+    "cfg5": dict(model="ViT-L/14@336px", encode="image", batch=128, rows=1_000_000, queries=128, baseline="configs[4]"),
+}
+
 
 def gemm_flops_per_forward(cfg, B):
-    """Algorithmic FLOPs of the GEMM launches of one vision forward (2 per multiply-add)."""
+    """Algorithmic FLOPs of the GEMM launches of one tower forward (2 per multiply-add) and their count."""
     T, d, m, L, E = cfg.tokens, cfg.width, cfg.mlp, cfg.layers, cfg.embed_dim
     rows = B * T
     per_layer = 2 * rows * d * (3 * d) + 2 * rows * d * d + 2 * rows * d * m + 2 * rows * m * d
-    patch = 2 * (B * (T - 1)) * cfg.patch_k * d
     proj = 2 * B * d * E
-    return patch + L * per_layer + proj, 1 + 4 * L + 1
+    if cfg.kind == "vision":
+        patch = 2 * (B * (T - 1)) * cfg.patch_k * d
+        return patch + L * per_layer + proj, 1 + 4 * L + 1
+    return L * per_layer + proj, 4 * L + 1
 
 
 def host_cores():
@@ -63,10 +75,10 @@ def host_cores():
 
 
 # BASELINE.json's metric string, verbatim
-METRIC = "images/sec encode + Mqueries/sec top-10 over 1M\u00d7512 gallery, 1\u21928 MI355X"
+METRIC = "images/sec encode + Mqueries/sec top-10 over 1M×512 gallery, 1→8 MI355X"
 
 
-def cpu_baseline(model_cfg, cores):
+def cpu_baseline(model_cfg, cores, batch, rows, queries, embed):
     """Bounded CPU sample on this box's host cores: the fp32 oracle for encode, the reference's torch
     expression for scoring + top-k.  Reported beside the GPU number; never part of it."""
     from mmr_amd import synth, weights
@@ -74,7 +86,7 @@ def cpu_baseline(model_cfg, cores):
 
     torch.set_num_threads(cores)
     w = weights.make_vision_weights(model_cfg.vision)
-    n_img = 2 * BATCH                                         # two steps' images (~9 s of CPU work)
+    n_img = 2 * batch                                         # two steps' images (~9 s of CPU work)
     px = synth.synth_images(n_img, model_cfg.vision.image_size, seed=2)
     with torch.no_grad():
         clip_ref.encode_image(w, model_cfg.vision, px[:4])
@@ -83,24 +95,85 @@ def cpu_baseline(model_cfg, cores):
             clip_ref.l2_normalize(clip_ref.encode_image(w, model_cfg.vision, px[i:i + 128]))
         t_enc = time.perf_counter() - t0
     enc_ips = n_img / t_enc
-    n_gal, n_q, reps = GALLERY_ROWS, QUERIES, 3               # the full gallery, one step's queries, three times (~4 s)
-    gal = synth.synth_unit_rows(n_gal, EMBED, seed=3)
-    q = synth.synth_unit_rows(n_q, EMBED, seed=4)
+    reps = 3                                                  # the full gallery, one step's queries, three times (~4 s)
+    gal = synth.synth_unit_rows(rows, embed, seed=3)
+    q = synth.synth_unit_rows(queries, embed, seed=4)
     search_ref.reference_expression_topk(gal[:1000], q, TOPK, 100.0)
     t0 = time.perf_counter()
     for _ in range(reps):
         search_ref.reference_expression_topk(gal, q, TOPK, 100.0)
     t_s = time.perf_counter() - t0
-    pairs_per_s = reps * n_gal * n_q / t_s
-    t_step = BATCH / enc_ips + QUERIES * GALLERY_ROWS / pairs_per_s
+    pairs_per_s = reps * rows * queries / t_s
+    t_step = batch / enc_ips + queries * rows / pairs_per_s
     return {
-        "value": round(BATCH / t_step, 3), "unit": "images/s", "cores": cores, "kind": "port",
+        "value": round(batch / t_step, 3), "unit": "images/s", "cores": cores, "kind": "port",
         "sample": (f"oracle/clip_ref.py fp32 encode of {n_img} images ({enc_ips:.1f} img/s, {t_enc:.1f} s) + reference "
-                   f"torch expression 100*F@q.T + topk({TOPK}) on {n_gal}x{EMBED} fp32 x {n_q} queries x {reps} "
-                   f"({pairs_per_s / 1e9:.2f} Gpairs/s, {t_s:.1f} s), scaled to one {BATCH}-image / {QUERIES}-query / "
-                   f"{GALLERY_ROWS}-row step; torch {torch.__version__}, {cores} threads"),
+                   f"torch expression 100*F@q.T + topk({TOPK}) on {rows}x{embed} fp32 x {queries} queries x {reps} "
+                   f"({pairs_per_s / 1e9:.2f} Gpairs/s, {t_s:.1f} s), scaled to one {batch}-image / {queries}-query / "
+                   f"{rows}-row step; torch {torch.__version__}, {cores} threads"),
         "encode_images_per_s": round(enc_ips, 2), "search_gpairs_per_s": round(pairs_per_s / 1e9, 3),
     }
+
+
+def unit_rows_on_device(n, e, seed, dev):
+    """[n,e] L2-normalised bf16 rows generated on the device (a 1-10M row shard is too slow to make on the host)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    out = torch.empty(n, e, dtype=torch.bfloat16, device=dev)
+    for s in range(0, n, 1 << 18):
+        x = torch.randn(min(n, s + (1 << 18)) - s, e, generator=g, device=dev)
+        out[s:s + x.shape[0]] = (x / x.norm(dim=-1, keepdim=True)).bfloat16()
+    return out
+
+
+def verify_sharded(index, sharded, gal, queries, k, dev, dist, use_dist):
+    """Proof that the merged list is the exact global top-k (outside the timed region; collectives allowed).
+    Returns ("ok", details) or ("FAILED: ...", details)."""
+    qd = queries.double()
+    if sharded:
+        score, gidx, d64 = index.search_async(queries, k, 1.0).result(return_dot64=True)
+        offset, n_local = index.offset, gal.shape[0]
+        local = index._index
+    else:
+        score, gidx, d64 = index.search(queries, k, 1.0, return_dot64=True)
+        offset, n_local = 0, gal.shape[0]
+        local = index
+    Q = queries.shape[0]
+    problems = []
+    # (a) every returned id re-scored by the rank that owns it
+    mine = (gidx >= offset) & (gidx < offset + n_local)
+    rows = gal[(gidx - offset).clamp(0, n_local - 1).reshape(-1)].double().reshape(Q, k, -1)
+    re = (rows * qd.unsqueeze(1)).sum(-1)
+    re = torch.where(mine, re, torch.zeros_like(re))
+    owners = mine.to(torch.int32)
+    if use_dist:
+        dist.all_reduce(re)
+        dist.all_reduce(owners)
+    if not bool((owners == 1).all()):
+        problems.append("an id is owned by no rank or by several")
+    err = float((re - d64).abs().max())
+    if not err < 1e-12:
+        problems.append(f"re-scored dot differs from the merged dot64 by {err:.3e}")
+    # (b) order and uniqueness
+    if not bool(((d64[:, :-1] > d64[:, 1:]) | ((d64[:, :-1] == d64[:, 1:]) & (gidx[:, :-1] < gidx[:, 1:]))).all()):
+        problems.append("merged list is not in (-dot, +id) order")
+    # (c) nothing outside the candidates can beat the k-th: merged k-th >= every rank's local (k+1)-th
+    _, _, ld = local.search(queries, k + 1, 1.0, return_dot64=True)
+    nxt = ld[:, k].clone()
+    if use_dist:
+        dist.all_reduce(nxt, op=dist.ReduceOp.MAX)
+    if not bool((d64[:, k - 1] >= nxt).all()):
+        problems.append("a rank's local (k+1)-th row beats the merged k-th")
+    # (d) all ranks hold the same answer
+    if use_dist:
+        chk = torch.stack([gidx.double().sum(), d64.sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not bool((lo == hi).all()):
+            problems.append("ranks disagree on the merged result")
+    detail = {"rescored_max_abs_err": err, "queries": Q, "k": k,
+              "checks": "owner re-score == merged dot64; (-dot,+id) order; merged k-th >= every local (k+1)-th; ranks agree"}
+    return ("ok" if not problems else "FAILED: " + "; ".join(problems)), detail
 
 
 def main():
@@ -108,7 +181,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS), help="workload (SURVEY 8d names); default cfg2 = BASELINE configs[1]")
+    ap.add_argument("--model", default=None, help="override the config's model (custom workload)")
+    ap.add_argument("--batch", type=int, default=None, help="override images/texts per rank per step")
+    ap.add_argument("--rows", type=int, default=None, help="override gallery rows per rank")
+    ap.add_argument("--queries", type=int, default=None, help="override queries per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
     args = ap.parse_args()
 
     # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on
@@ -116,6 +195,17 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+
+    C = dict(CONFIGS[args.config])
+    custom = []
+    for key in ("model", "batch", "rows", "queries"):
+        v = getattr(args, key)
+        if v is not None and v != C[key]:
+            C[key] = v
+            custom.append(f"{key}={v}")
+    MODEL, ENC, BATCH, ROWS, QUERIES = C["model"], C["encode"], C["batch"], C["rows"], C["queries"]
+    if ENC == "text" and QUERIES != BATCH:
+        QUERIES = BATCH                      # the encoded prompts ARE the queries
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -139,31 +229,51 @@ def main():
     import mmr_amd
     from mmr_amd import _lib, search, synth
 
-    model, _ = mmr_amd.load(MODEL, device=dev)
+    model, _ = mmr_amd.load(MODEL, device=dev, weights="synthetic")     # no checkpoint is reachable offline
     model.bfloat16()
     cfg = model.cfg
-    g = torch.Generator(device=dev).manual_seed(2 + rank)
-    pixels = torch.randn(BATCH, 3, cfg.vision.image_size, cfg.vision.image_size, generator=g, device=dev,
-                         dtype=torch.float32).bfloat16()
-    g = torch.Generator(device=dev).manual_seed(3 + rank)
-    gal = torch.empty(GALLERY_ROWS, EMBED, dtype=torch.bfloat16, device=dev)
-    for s in range(0, GALLERY_ROWS, 1 << 18):
-        e = min(GALLERY_ROWS, s + (1 << 18))
-        x = torch.randn(e - s, EMBED, generator=g, device=dev)
-        gal[s:e] = (x / x.norm(dim=-1, keepdim=True)).bfloat16()
+    EMBED = cfg.embed_dim
+    tower_cfg = cfg.text if ENC == "text" else cfg.vision
+    pixels = ids = None
+    if ENC == "image":
+        g = torch.Generator(device=dev).manual_seed(2 + rank)
+        pixels = torch.randn(BATCH, 3, cfg.vision.image_size, cfg.vision.image_size, generator=g, device=dev,
+                             dtype=torch.float32).bfloat16()
+    elif ENC == "text":
+        ids = synth.synth_token_ids(BATCH, cfg.text.tokens, cfg.text.vocab, seed=5).to(dev)   # replicated: same queries on every rank
+    gal = unit_rows_on_device(ROWS, EMBED, 3 + rank, dev)
     queries = synth.synth_unit_rows(QUERIES, EMBED, seed=4).bfloat16().to(dev)   # replicated on every rank
     index = search.ShardedGalleryIndex(gal, group=None) if use_dist else search.GalleryIndex(gal)
 
-    def step(ev=None):
-        if ev:
-            ev[0].record()
-        feats = model.encode_image(pixels, normalize=True)
-        if ev:
-            ev[1].record()
-        out = index.search(queries, TOPK, 1.0)
-        if ev:
-            ev[2].record()
-        return feats, out
+    def encode():
+        if ENC == "image":
+            return model.encode_image(pixels, normalize=True)
+        if ENC == "text":
+            return model.encode_text(ids, normalize=True)
+        return None
+
+    def run_steps(n, events=None):
+        """n steps; with a process group the all-gather of step i overlaps step i+1 (drained at the end)."""
+        pending = None
+        for i in range(n):
+            ev = events[i] if events else None
+            if ev:
+                ev[0].record()
+            feats = encode()
+            if ev:
+                ev[1].record()
+            q = feats if ENC == "text" else queries
+            if use_dist:
+                nxt = index.search_async(q, TOPK, 1.0)
+                if pending is not None:
+                    pending.result()
+                pending = nxt
+            else:
+                index.search(q, TOPK, 1.0)
+            if ev:
+                ev[2].record()
+        if pending is not None:
+            pending.result()
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -171,23 +281,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(events[i])
+    run_steps(args.steps, events)
     fence()
     elapsed = time.perf_counter() - t0
 
     # Per-kernel durations for the roofline legs: the SAME K steps again with a HIP event pair around
     # every launch, recorded on the launch stream.  Kept out of the timed region on purpose: an event
-    # pair per launch (~110 launches/step) serialises the queue and costs ~15% of the step time.
-    _lib.prof_enable(True, max(4096, 160 * args.steps))
-    for i in range(args.steps):
-        step()
+    # pair per launch serialises the queue and costs ~15% of the step time.
+    _lib.prof_enable(True, max(4096, 700 * args.steps))
+    run_steps(args.steps)
     fence()
     _lib.prof_enable(False)
     prof = _lib.prof_read()
@@ -200,65 +307,127 @@ def main():
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     srch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
 
+    # ---- outside the timed region: verification, fallback count, query sweep
+    vq = encode() if ENC == "text" else queries
+    verify, verify_detail = verify_sharded(index, use_dist, gal, vq, TOPK, dev, dist, use_dist)
+    local_index = index._index if use_dist else index
+    status = local_index.search(vq, TOPK, 1.0, return_status=True)[-1]
+    fallback = int(status.sum())
+
+    def scan_bytes_for(q):
+        return ROWS * EMBED * 2 + q * EMBED * 2 + q * TOPK * 8     # gallery once + queries + results
+
+    sweep = None
+    if args.config == "cfg2" and not args.no_sweep:
+        sweep = {}
+        for Q in (1, 32, 256, 1024):
+            qs = synth.synth_unit_rows(Q, EMBED, seed=40 + Q).bfloat16().to(dev)
+            for _ in range(3):
+                local_index.search(qs, TOPK, 1.0)
+            torch.cuda.synchronize(dev)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 10
+            e0.record()
+            for _ in range(reps):
+                local_index.search(qs, TOPK, 1.0)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / reps
+            _lib.prof_enable(True, 4096)
+            for _ in range(reps):
+                local_index.search(qs, TOPK, 1.0)
+            torch.cuda.synchronize(dev)
+            _lib.prof_enable(False)
+            p = _lib.prof_read()
+            scan_ms_q = p["scan"][0] / reps                      # all scan passes of one search (4 passes at Q=1024)
+            passes = max(1, p["scan"][1] // reps)
+            gbs = (ROWS * EMBED * 2 * passes + Q * EMBED * 2 + Q * TOPK * 8) / (scan_ms_q * 1e-3) / 1e9
+            sweep[str(Q)] = {"search_ms": round(ms, 4), "queries_per_s": round(Q / (ms * 1e-3), 1),
+                             "gpairs_per_s": round(Q * ROWS / (ms * 1e-3) / 1e9, 2),
+                             "scan_ms": round(scan_ms_q, 4), "scan_passes": passes, "scan_gb_per_s": round(gbs, 1),
+                             "scan_frac_of_hbm_peak": round(gbs / PEAK_HBM_GBS, 4),
+                             "scan_tflops": round(2.0 * Q * ROWS * EMBED / (scan_ms_q * 1e-3) / 1e12, 1)}
+
     if rank == 0:
-        gflops, n_gemm = gemm_flops_per_forward(cfg.vision, BATCH)
         gemm_ms, gemm_n = prof["gemm"]
         scan_ms, scan_n = prof["scan"]
-        fwd = gemm_n / n_gemm if n_gemm else 0
-        gemm_tflops = (gflops * fwd) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        scan_bytes = GALLERY_ROWS * EMBED * 2 + QUERIES * EMBED * 2 + QUERIES * TOPK * 8
+        gemm_tflops, gflops, n_gemm = 0.0, 0, 0
+        if ENC != "none":
+            gflops, n_gemm = gemm_flops_per_forward(tower_cfg, BATCH)
+            fwd = gemm_n / n_gemm if n_gemm else 0
+            gemm_tflops = (gflops * fwd) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        scan_bytes = scan_bytes_for(QUERIES)
         scan_gbs = scan_bytes * scan_n / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        traffic = None
+        scan_tflops = 2.0 * QUERIES * ROWS * EMBED * scan_n / (scan_ms * 1e-3) / 1e12 if scan_ms > 0 else 0.0
+        traffic, tf = None, ""
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # newest round's PMC passes
-        tf = cands[-1] if cands else ""
-        if tf and os.path.exists(tf):
+        if cands and args.config == "cfg2" and not custom:
+            tf = cands[-1]
             try:
                 traffic = json.load(open(tf))
             except Exception:
                 traffic = None
+        traffic_src = (f"{os.path.relpath(tf, ROOT)} (replayed from the committed rocprofv3 --pmc passes of this workload; "
+                       "NOT measured in this run)") if traffic else None
+        unit = {"image": "images/s", "text": "texts/s", "none": "queries/s"}[ENC]
+        per_step_units = world * BATCH if ENC != "none" else QUERIES
+        enc_name = {"image": f"{MODEL} bf16 encode batch {BATCH}/GPU + ", "text": f"{MODEL} text tower bf16 on {BATCH} prompts (= the queries) + ",
+                    "none": ""}[ENC]
+        workload = (f"{enc_name}top-{TOPK} of {QUERIES} queries over {ROWS}x{EMBED} bf16 gallery rows/GPU "
+                    f"(BASELINE {C['baseline']}{'; CUSTOM ' + ' '.join(custom) if custom else ''})")
+        roof_gemm = {
+            "kernel": "gemm256_bf16_kernel / gemm_bf16_kernel / gemm_skinny_kernel (all epilogues)", "bound": "mfma",
+            "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
+            "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "traffic_source": traffic_src,
+            "avg_launch_us": round(gemm_ms / gemm_n * 1e3, 2) if gemm_n else None, "launches": gemm_n,
+            "algorithmic_gflop_per_launch": round(gflops / n_gemm / 1e9, 3) if n_gemm else None,
+            "measured": "HIP event pairs around each launch on the launch stream, second pass of the same K steps",
+        }
+        roof_scan = {
+            "kernel": f"scan_kernel<{EMBED}>", "bound": "hbm+mfma",
+            "achieved": round(scan_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(scan_gbs / PEAK_HBM_GBS, 4),
+            "mfma_achieved_tflops": round(scan_tflops, 1), "mfma_frac": round(scan_tflops / PEAK_BF16_TFLOPS, 4),
+            "note": f"at {QUERIES} resident queries the scan does {QUERIES} FLOP per gallery byte: it is paced by the matrix pipe "
+                    "as much as by HBM (both fractions given); at Q <= 64 it is HBM-paced (see search_sweep)",
+            "traffic": (traffic or {}).get("scan_bytes_per_launch"), "traffic_source": traffic_src,
+            "avg_launch_us": round(scan_ms / scan_n * 1e3, 2) if scan_n else None, "launches": scan_n,
+            "algorithmic_bytes_per_launch": scan_bytes,
+        }
         line = {
             "metric": METRIC,
-            "value": round(world * BATCH / (ms_per_step * 1e-3), 1),
-            "unit": "images/s",
+            "value": round(per_step_units / (ms_per_step * 1e-3), 1),
+            "unit": unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{MODEL} bf16 encode batch {BATCH}/GPU + top-{TOPK} of {QUERIES} queries over "
-                                   f"{GALLERY_ROWS}x{EMBED} bf16 gallery rows/GPU (BASELINE configs[1])",
-                       "encode_batch_per_gpu": BATCH, "gallery_rows_per_gpu": GALLERY_ROWS, "queries": QUERIES,
-                       "k": TOPK, "embed_dim": EMBED,
-                       "parallelism": f"dp{world} encode, gallery row-sharded x{world}, 1 all-gather of top-k"
-                                      if world > 1 else "single GPU",
+            "config": {"workload": workload, "name": args.config,
+                       "encode_batch_per_gpu": BATCH, "gallery_rows_per_gpu": ROWS, "gallery_rows_total": ROWS * world,
+                       "queries": QUERIES, "k": TOPK, "embed_dim": EMBED,
+                       "parallelism": (f"dp{world} encode (no collective), gallery row-sharded x{world}, 1 async all-gather of "
+                                       f"top-k per step overlapped with the next step") if world > 1 else "single GPU",
                        "weights": "seeded random init (no checkpoint reachable offline)"},
+            "verify": verify, "verify_detail": verify_detail,
+            "search_fallback_queries": fallback,
             "encode_ms": round(enc_ms, 4), "search_ms": round(srch_ms, 4),
-            "encode_images_per_s": round(world * BATCH / (enc_ms * 1e-3), 1),
             "search_queries_per_s": round(QUERIES / (srch_ms * 1e-3), 1),
             "search_mqueries_per_s": round(QUERIES / (srch_ms * 1e-3) / 1e6, 4),
-            "search_gpairs_per_s": round(QUERIES * GALLERY_ROWS * world / (srch_ms * 1e-3) / 1e9, 2),
-            "roofline": {
-                "kernel": "gemm256_bf16_kernel / gemm_bf16_kernel (all epilogues)", "bound": "mfma",
-                "achieved": round(gemm_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4),
-                "traffic": (traffic or {}).get("gemm_bytes_per_launch"),
-                "avg_launch_us": round(gemm_ms / gemm_n * 1e3, 2) if gemm_n else None, "launches": gemm_n,
-                "algorithmic_gflop_per_launch": round(gflops / n_gemm / 1e9, 3),
-                "measured": "HIP event pairs around each launch on the launch stream, second pass of the same K steps",
-            },
-            "roofline_search": {
-                "kernel": "scan_kernel<512>", "bound": "hbm",
-                "achieved": round(scan_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                "frac": round(scan_gbs / PEAK_HBM_GBS, 4),
-                "traffic": (traffic or {}).get("scan_bytes_per_launch"),
-                "avg_launch_us": round(scan_ms / scan_n * 1e3, 2) if scan_n else None, "launches": scan_n,
-                "algorithmic_bytes_per_launch": scan_bytes,
-            },
+            "search_gpairs_per_s": round(QUERIES * ROWS * world / (srch_ms * 1e-3) / 1e9, 2),
+            "roofline": roof_gemm if ENC != "none" else roof_scan,
+            "roofline_search": roof_scan,
             "kernel_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in prof.items() if k != "dropped"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if ENC != "none":
+            key = "encode_images_per_s" if ENC == "image" else "encode_texts_per_s"
+            line[key] = round(world * BATCH / (enc_ms * 1e-3), 1)
+        if sweep is not None:
+            line["search_sweep"] = sweep
+        if world == 1 and args.config == "cfg2" and not custom and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(cfg, host_cores())
+                line["cpu_baseline"] = cpu_baseline(cfg, host_cores(), BATCH, ROWS, QUERIES, EMBED)
             except Exception as ex:  # the baseline must never take the GPU number down with it
                 line["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": host_cores(), "kind": "port",
                                         "sample": f"failed: {ex!r}"}
@@ -267,6 +436,8 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if not verify.startswith("ok"):
+        raise SystemExit(f"bench verification failed: {verify}")
 
 
 if __name__ == "__main__":

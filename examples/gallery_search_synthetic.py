@@ -54,7 +54,7 @@ def main(argv=None):
     ap.add_argument("--classes", type=int, default=6)
     ap.add_argument("--per-class", type=int, default=200)
     ap.add_argument("--image-size", type=int, default=256)
-    ap.add_argument("--weights", default=None)
+    ap.add_argument("--weights", default="synthetic", help="checkpoint file, or \"synthetic\" (default here: seeded random weights)")
     args = ap.parse_args(argv)
     random.seed(1)
     torch.manual_seed(1)

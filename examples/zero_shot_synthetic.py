@@ -20,7 +20,7 @@ import mmr_amd as clip  # noqa: E402
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--model", default="ViT-B/32")
-    ap.add_argument("--weights", default=None, help="checkpoint file (OpenAI / HF / this package's naming)")
+    ap.add_argument("--weights", default="synthetic", help="checkpoint file (OpenAI / HF / this package naming), or \"synthetic\" (default here: seeded random weights)")
     ap.add_argument("--bpe", default=None, help="CLIP BPE merge table; without it prompts are synthetic token ids")
     args = ap.parse_args(argv)
 

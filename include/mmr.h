@@ -50,13 +50,32 @@ size_t mmr_search_workspace_bytes(int64_t N, int E, int Q, int k);
  *   idx[Q,k] int32 row ids (-1 past N), score[Q,k] = (float)(dot64*scale),
  *   dot64[Q,k] (nullable) the exact fp64 dot products used for ranking,
  *   status[Q] (nullable): 0 = MFMA scan + certified exact re-rank, 1 = exhaustive exact path.
- *   scale must be > 0.  gallery_norm_bound: upper bound on the L2 norm of any gallery row
- *   (1.0 for a normalised gallery); it only sizes the certification margin, never the result.
+ *   scale must be > 0.
+ *   gallery_norm_bound sizes the margin of the fast path's exactness certificate
+ *   (8e-5 * ||q|| * bound, above the worst-case fp32 MFMA accumulation error for E <= 1024):
+ *     <= 0 : measured by this call from the gallery itself (one extra streaming pass) -- always sound;
+ *     >  0 : PRECONDITION: no gallery row has a larger L2 norm (1.0 for a normalised gallery).  An
+ *            understated bound can let the certificate pass wrongly, i.e. return a top-k that is not exact;
+ *            an overstated one only sends more queries down the exhaustive path.
  * Ranking is on fp64 dot products accumulated in the fixed order documented in
  * oracle/search_ref.c, so indices are bit-reproducible against the CPU oracle. */
 int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
                     float scale, float gallery_norm_bound, int32_t *idx, float *score, double *dot64,
                     int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
+
+/* bound_out[0] (device float) = the largest row L2 norm of gallery[N,E] (0 for N = 0), rounded up.
+ * One HBM-bound pass; an index that is searched many times measures once and hands the scalar to
+ * mmr_cosine_topk_ex. */
+int mmr_gallery_norm_bound(const void *gallery, mmr_dtype dtype, int64_t N, int E, float *bound_out, void *stream);
+
+/* mmr_cosine_topk with the norm bound read on the device: the margin uses
+ * max(gallery_norm_bound, *gallery_norm_bound_dev) (either may be absent: <= 0 / NULL; both absent =
+ * measured in the call), so a caller-supplied number can widen the margin but never shrink it below
+ * the measured one.  No host read of the scalar: the call stays asynchronous and graph-capturable. */
+int mmr_cosine_topk_ex(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
+                       float scale, float gallery_norm_bound, const float *gallery_norm_bound_dev, int32_t *idx,
+                       float *score, double *dot64, int32_t *status, void *workspace, size_t workspace_bytes,
+                       void *stream);
 
 /* out[Q,N] (fp32) = (float)(dot64 * scale): the materialised score matrix for small N. */
 int mmr_similarity(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, float scale,
@@ -129,6 +148,13 @@ int mmr_tower_param_span(const mmr_tower_cfg *cfg, int param, int layer, size_t 
 
 typedef struct mmr_tower mmr_tower;
 
+/* Workspace status word: every forward call (mmr_tower_forward / mmr_vit_encode_image / mmr_text_encode /
+ * mmr_bert_forward*) zeroes the int32 at workspace offset 0 and the embedding kernels OR bits into it:
+ *   bit 0 = a token id (or token type id) was out of range and was clamped.
+ * The library never reads it back (no sync); a caller that feeds ids produced on the device reads it when it
+ * chooses to synchronise.  Ids on the host are range-checked by the host shim before the call. */
+#define MMR_STATUS_BAD_TOKEN_ID 1
+
 /* `weights` is a device blob laid out per mmr_tower_param_span; it must outlive the tower. */
 int mmr_tower_create(const mmr_tower_cfg *cfg, const void *weights, size_t weights_bytes, mmr_tower **out);
 void mmr_tower_destroy(mmr_tower *t);
@@ -152,6 +178,14 @@ int mmr_text_encode(mmr_tower *t, const int32_t *ids, int N, void *out, mmr_dtyp
 size_t mmr_bert_workspace_bytes(const mmr_tower *t, int N, int T);
 int mmr_bert_forward(mmr_tower *t, const int32_t *ids, int N, int T, void *out, mmr_dtype out_dtype, int normalize,
                      int tap_after, float *tap, void *workspace, size_t workspace_bytes, void *stream);
+/* The `text_encoder(**inputs)` form (reference CLIP/union_dataset.py:312-314, CLIP-Chinese/lab_chinese.py:90-92):
+ * the tokenizer's whole output.  token_type_ids[N,T] int32 (nullable = all 0; values 0/1 select the type
+ * embedding row); attention_mask[N,T] int32 (nullable = all 1; 0 = padding key: it receives no attention weight,
+ * like HF's additive -inf mask; padded QUERY rows are still computed, as in HF, and do not reach the pooled
+ * output, which reads token 0). */
+int mmr_bert_forward_masked(mmr_tower *t, const int32_t *ids, const int32_t *token_type_ids,
+                            const int32_t *attention_mask, int N, int T, void *out, mmr_dtype out_dtype, int normalize,
+                            int tap_after, float *tap, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Same forward with a tap on the fp32 residual stream for stage-level parity tests:
  * tap_after = -1 copies h after the embedding (+pre-LN for vision); i >= 0 after block i.
@@ -219,6 +253,8 @@ int mmr_debug_layernorm(const float *h, const float *w, const float *b, void *x,
                         void *stream);
 /* o_bf16[B*T, d] = softmax(QK^T/8 (+causal)) V per head, from packed qkv_bf16[B*T, 3d] */
 int mmr_debug_attention(const void *qkv, void *o, int B, int T, int heads, int causal, void *stream);
+/* the non-causal form with a key-padding mask key_mask[B,T] int32 (0 = masked key) */
+int mmr_debug_attention_masked(const void *qkv, void *o, int B, int T, int heads, const int32_t *key_mask, void *stream);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,10 @@ def lib():
     L.mmr_search_workspace_bytes.argtypes = [i64, i32, i32, i32]
     L.mmr_cosine_topk.restype = i32
     L.mmr_cosine_topk.argtypes = [vp, vp, i32, i32, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]
+    L.mmr_cosine_topk_ex.restype = i32
+    L.mmr_cosine_topk_ex.argtypes = [vp, vp, i32, i32, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.mmr_gallery_norm_bound.restype = i32
+    L.mmr_gallery_norm_bound.argtypes = [vp, i32, i64, i32, vp, vp]
     L.mmr_similarity.restype = i32
     L.mmr_similarity.argtypes = [vp, vp, i32, i32, i64, i32, f32, vp, vp]
     L.mmr_l2norm_rows.restype = i32
@@ -93,6 +97,10 @@ def lib():
         L.mmr_bert_workspace_bytes.argtypes = [vp, i32, i32]
         L.mmr_bert_forward.restype = i32
         L.mmr_bert_forward.argtypes = [vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, sz, vp]
+        L.mmr_bert_forward_masked.restype = i32
+        L.mmr_bert_forward_masked.argtypes = [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp, vp, sz, vp]
+        L.mmr_debug_attention_masked.restype = i32
+        L.mmr_debug_attention_masked.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.mmr_debug_gemm.restype = i32
         L.mmr_debug_gemm.argtypes = [i32, vp, vp, i32, i32, i32, vp, vp, vp]
         L.mmr_debug_layernorm.restype = i32

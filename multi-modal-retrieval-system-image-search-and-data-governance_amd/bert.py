@@ -3,9 +3,14 @@
 Mirrors how the reference uses it (code/test_taiyi.py:12,24; CLIP-Chinese/lab_chinese.py:81-93):
     text_encoder = BertForSequenceClassification.from_pretrained("IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chinese").eval()
     text_features = text_encoder(text).logits          # text = tokenizer(..., padding=True)['input_ids']
-The call passes ids only, so all tokens (pads included) attend to each other with token type 0; that is what
-csrc/tower.hip::mmr_bert_forward computes.  Weights / vocabulary are not reachable offline: pass ``weights=``
-(names in weights.make_bert_weights) or get the seeded synthetic ones the golden fixtures use.
+That call passes ids only, so all tokens (pads included) attend to each other with token type 0
+(csrc/tower.hip::mmr_bert_forward).  The other spelling the reference uses,
+    inputs = text_tokenizer([text], return_tensors="pt", padding=True).to(device); text_encoder(**inputs).logits
+(CLIP/union_dataset.py:312-314, CLIP-Chinese/lab_chinese.py:90-92) hands over the tokenizer's whole output:
+``attention_mask`` becomes a key-padding mask inside the attention kernels and ``token_type_ids`` select the
+type-embedding row (mmr_bert_forward_masked), so a padded multi-text batch matches HF.
+Weights / vocabulary are not reachable offline: pass ``weights=`` (a checkpoint, or names as in
+weights.make_bert_weights); ``weights="synthetic"`` asks for the seeded random ones the golden fixtures use.
 """
 import ctypes
 from types import SimpleNamespace
@@ -94,8 +99,19 @@ class BertTextEncoder:
     def dtype(self):
         return self._dtype
 
+    def _ids_like(self, t, name, shape):
+        t = torch.as_tensor(t)
+        if t.dim() == 1:
+            t = t.unsqueeze(0)
+        if t.dtype.is_floating_point or t.dtype == torch.bool:
+            t = t.to(torch.int32)
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"{name} {tuple(t.shape)} does not match input_ids {tuple(shape)}")
+        return t.to(device=self.device, dtype=torch.int32).contiguous()
+
     @torch.no_grad()
-    def logits(self, input_ids: torch.Tensor, normalize: bool = False, tap_after: int = -1,
+    def logits(self, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+               token_type_ids: Optional[torch.Tensor] = None, normalize: bool = False, tap_after: int = -1,
                tap: Optional[torch.Tensor] = None) -> torch.Tensor:
         if input_ids is None:
             raise ValueError("You have to specify input_ids")
@@ -107,9 +123,13 @@ class BertTextEncoder:
         N, T = ids.shape
         if not 1 <= T <= self.cfg.max_positions:
             raise ValueError(f"sequence length {T} outside [1,{self.cfg.max_positions}]")
-        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.cfg.vocab):
+        # host-resident ids are range-checked here; device-resident ones by the embedding kernel (status word), so a
+        # call never reads device data back
+        if not ids.is_cuda and ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.cfg.vocab):
             raise IndexError(f"token id outside [0,{self.cfg.vocab})")
         ids = ids.to(device=self.device, dtype=torch.int32).contiguous()
+        mask = None if attention_mask is None else self._ids_like(attention_mask, "attention_mask", (N, T))
+        types = None if token_type_ids is None else self._ids_like(token_type_ids, "token_type_ids", (N, T))
         out = torch.empty(N, self.cfg.embed_dim, dtype=self._dtype, device=self.device)
         with torch.cuda.device(self.device):
             for s in range(0, N, self.max_batch):
@@ -117,15 +137,25 @@ class BertTextEncoder:
                 need = self.L.mmr_bert_workspace_bytes(self.handle, n, T)
                 if self._ws is None or self._ws.numel() < need:
                     self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-                _lib.check(self.L.mmr_bert_forward(self.handle, ids[s:s + n].data_ptr(), n, T, out[s:s + n].data_ptr(),
-                                                   _lib.dtype_code(self._dtype), int(bool(normalize)), int(tap_after),
-                                                   _lib.ptr(tap), self._ws.data_ptr(), self._ws.numel(),
-                                                   _lib.stream_ptr(self.device)))
+                _lib.check(self.L.mmr_bert_forward_masked(
+                    self.handle, ids[s:s + n].data_ptr(), _lib.ptr(None if types is None else types[s:s + n]),
+                    _lib.ptr(None if mask is None else mask[s:s + n]), n, T, out[s:s + n].data_ptr(),
+                    _lib.dtype_code(self._dtype), int(bool(normalize)), int(tap_after), _lib.ptr(tap),
+                    self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device)))
         return out
 
-    def __call__(self, input_ids=None, **_):
-        """``text_encoder(text).logits`` surface."""
-        return SimpleNamespace(logits=self.logits(input_ids))
+    def id_errors(self) -> bool:
+        """True if the last call's (last slice's) kernels saw a token / token-type id out of range (clamped).
+        Synchronises; for callers whose ids were produced on the GPU."""
+        return self._ws is not None and int(self._ws[:4].view(torch.int32)[0]) != 0
+
+    def __call__(self, input_ids=None, attention_mask=None, token_type_ids=None, **_):
+        """``text_encoder(text).logits`` / ``text_encoder(**tokenizer_output).logits`` surface."""
+        return SimpleNamespace(logits=self.logits(input_ids, attention_mask, token_type_ids))
+
+
+SYNTHETIC = "synthetic"
+_SYNTHETIC_ONLY = ("tiny-bert-test",)
 
 
 def load_text_encoder(name: str = "IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chinese", device="cuda",
@@ -133,13 +163,17 @@ def load_text_encoder(name: str = "IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chine
     """Counterpart of ``BertForSequenceClassification.from_pretrained(name)`` for the Taiyi text tower.
     ``weights``: a checkpoint path (safetensors / state-dict .bin) or a state dict in HF or this package's
     naming; ``name`` may also be a checkpoint file or a directory holding ``model.safetensors`` /
-    ``pytorch_model.bin`` (the from_pretrained layout).  Without any, seeded synthetic weights."""
+    ``pytorch_model.bin`` (the from_pretrained layout).  Nothing can be downloaded here: without a checkpoint the
+    call raises FileNotFoundError unless random weights are asked for on purpose with ``weights="synthetic"``."""
     import os
 
     from . import checkpoint
 
+    synthetic = isinstance(weights, str) and weights == SYNTHETIC
+    if synthetic:
+        weights = None
     path = weights if isinstance(weights, (str, os.PathLike)) else None
-    if weights is None:
+    if weights is None and not synthetic:
         if os.path.isfile(name):
             path = name
         elif os.path.isdir(name):
@@ -163,5 +197,10 @@ def load_text_encoder(name: str = "IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chine
             raise ValueError(f"checkpoint geometry {geom(inferred)} does not match {name} {geom(cfg)}")
     else:
         cfg = get_bert_config(name)
+        if not synthetic and name not in _SYNTHETIC_ONLY:
+            raise FileNotFoundError(
+                f"no checkpoint for {name!r}: not a file or a from_pretrained directory, and this environment cannot "
+                f"download. Pass weights=<file or state dict>, or ask for random weights explicitly with "
+                f"weights={SYNTHETIC!r}.")
         weights = make_bert_weights(cfg, seed=seed)
     return BertTextEncoder(cfg, weights, device)

@@ -133,6 +133,11 @@ class _Tower:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    def status_word(self) -> int:
+        """The forward pass's status word (include/mmr.h: first int32 of the workspace; bit 0 = a token id was out of
+        range and clamped).  Reading it synchronises."""
+        return 0 if self._ws is None else int(self._ws[:4].view(torch.int32)[0])
+
     def forward(self, inp: torch.Tensor, out_dtype: torch.dtype, normalize: bool, tap_after: int = -1,
                 tap: Optional[torch.Tensor] = None) -> torch.Tensor:
         B = inp.shape[0]
@@ -164,6 +169,9 @@ class CLIP:
             self.visual = _Tower(cfg.vision, weights, device, fold_ln)
             self.text = _Tower(cfg.text, weights, device, fold_ln)
         self.logit_scale = weights["logit_scale"].detach().clone().to(device=device, dtype=torch.float32)
+        # exp(logit_scale) as a host number, computed once from the host copy of the weights: forward() must not
+        # read a device scalar back (a host sync per call)
+        self._logit_scale_exp = float(weights["logit_scale"].detach().double().cpu().exp())
         # Output dtype.  Arithmetic is always bf16-in / fp32-accumulate MFMA; the RETURNED tensors default
         # to float32 because the reference's callers do `.cpu().numpy()` on them
         # (code/search_image.py:109,158), which numpy cannot do for bf16.  `.bfloat16()` switches the
@@ -259,9 +267,17 @@ class CLIP:
             raise ValueError(f"expected token ids [N,{T}], got {tuple(text.shape)}")
         if text.dtype.is_floating_point:
             raise TypeError("token ids must be an integer tensor")
-        if text.numel() and (int(text.min()) < 0 or int(text.max()) >= self.cfg.text.vocab):
+        # Range check without a device round trip: ids that are still on the host (what clip.tokenize returns) are
+        # checked here; ids already on the GPU are checked by the embedding kernel itself, which clamps them and
+        # raises the tower's status word (read it with `model.text_id_errors()` -- that read is the only sync).
+        if not text.is_cuda and text.numel() and (int(text.min()) < 0 or int(text.max()) >= self.cfg.text.vocab):
             raise IndexError(f"token id outside [0,{self.cfg.text.vocab})")
         return text.to(device=self.device, dtype=torch.int32).contiguous()
+
+    def text_id_errors(self) -> bool:
+        """True if the LAST encode_text call saw a token id outside [0, vocab) (the kernel clamped it).
+        Synchronises the device; meant for callers that feed ids produced on the GPU."""
+        return self.text.status_word() != 0
 
     @torch.no_grad()
     def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
@@ -287,7 +303,7 @@ class CLIP:
 
         img = self.encode_image(image, normalize=True).to(torch.float32)
         txt = self.encode_text(text, normalize=True).to(torch.float32)
-        scale = float(self.logit_scale.exp())
+        scale = self._logit_scale_exp
         logits_per_image = similarity(img, txt, scale)            # [B,N] = img @ txt.T * scale
         if logits_per_image.dim() == 1:
             logits_per_image = logits_per_image.unsqueeze(1)
@@ -296,16 +312,22 @@ class CLIP:
     __call__ = forward
 
 
-def _preprocess_factory(n_px: int, device: torch.device):
+def _preprocess_factory(n_px: int, device: torch.device, model=None, pixel_dtype: Optional[torch.dtype] = None):
     """The ``preprocess`` callable ``clip.load`` returns: Resize(n_px, BICUBIC) -> CenterCrop(n_px) ->
     ToTensor -> Normalize(CLIP mean/std) (reference use sites code/search_image.py:127,155; constants
     code/custom.py:28).  The decoded uint8 pixels are uploaded once and everything else runs in
     csrc/preprocess.hip, bit-exact to Pillow's resize.  Accepts a PIL image, an HWC
-    uint8 array or tensor; returns float32 [3,n_px,n_px] ON THE MODEL'S DEVICE (the reference's following
-    ``.unsqueeze(0).cuda()`` / ``torch.stack(...).cuda()`` are then no-ops)."""
+    uint8 array or tensor; returns [3,n_px,n_px] ON THE MODEL'S DEVICE (the reference's following
+    ``.unsqueeze(0).cuda()`` / ``torch.stack(...).cuda()`` are then no-ops).
+
+    Output dtype: ``pixel_dtype`` if given (``load(..., pixel_dtype=torch.bfloat16)``), else the model's dtype at call
+    time -- float32 for the default model (what the reference's ``preprocess`` returns), bfloat16 after
+    ``model.bfloat16()``.  The encoder rounds pixels to bf16 on its way into the matrix cores either way, so the
+    features are bit-identical; bf16 pixels let patch-32 towers gather patches inside the GEMM's A-tile loads
+    (no im2col pass) and halve the pixel bytes."""
     from .preprocess import preprocess_image
 
-    def preprocess(img) -> torch.Tensor:
+    def preprocess(img, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
         if isinstance(img, torch.Tensor):
             x = img
         else:
@@ -317,9 +339,52 @@ def _preprocess_factory(n_px: int, device: torch.device):
         if x.dtype != torch.uint8 or x.dim() != 3 or x.shape[2] != 3:
             raise TypeError("preprocess expects a PIL image or a uint8 [H,W,3] array/tensor "
                             f"(got {x.dtype} {tuple(x.shape)})")
-        return preprocess_image(x.to(device, non_blocking=True), n_px)
+        dt = dtype or pixel_dtype or (model.dtype if model is not None else torch.float32)
+        return preprocess_image(x.to(device, non_blocking=True), n_px, out_dtype=dt)
 
     return preprocess
+
+
+class BatchFeature(dict):
+    """What ``CLIPProcessor.__call__`` returns: a dict with attribute access and ``.to(device)``."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def to(self, *args, **kwargs):
+        return BatchFeature({k: (v.to(*args, **kwargs) if isinstance(v, torch.Tensor) else v) for k, v in self.items()})
+
+
+class ClipProcessor:
+    """``CLIPProcessor`` spelling of the preprocess step, as the reference's HF flow calls it
+    (code/test_taiyi.py:18-19 ``processor(images=img, return_tensors="pt")`` -> ``get_image_features(**image)``;
+    CLIP-Chinese/lab_chinese.py:84).  images: one PIL image / uint8 HWC array or a list -> ``pixel_values``
+    [B,3,S,S] on the model's device (resize-shorter-side bicubic, centre crop, /255, CLIP mean/std: the same
+    csrc/preprocess.hip kernels as ``preprocess``).  text: strings -> ``input_ids`` / ``attention_mask`` through the
+    CLIP BPE when its merge table is available (``tokenize``)."""
+
+    def __init__(self, preprocess, context_length: int = _CONTEXT):
+        self.preprocess, self.context_length = preprocess, context_length
+
+    def __call__(self, text=None, images=None, return_tensors: str = "pt", padding=True, **_):
+        if return_tensors != "pt":
+            raise ValueError("only return_tensors='pt' is supported")
+        out = BatchFeature()
+        if images is not None:
+            single = not isinstance(images, (list, tuple))
+            imgs = [images] if single else list(images)
+            out["pixel_values"] = torch.stack([self.preprocess(im) for im in imgs])
+        if text is not None:
+            ids = tokenize(text, self.context_length)
+            out["input_ids"] = ids
+            eot = ids.argmax(-1, keepdim=True)
+            out["attention_mask"] = (torch.arange(ids.shape[1])[None, :] <= eot).to(torch.int64)
+        if not out:
+            raise ValueError("You have to specify either text or images")
+        return out
 
 
 def _find_checkpoint(name: str, download_root: Optional[str]) -> Optional[str]:
@@ -336,16 +401,27 @@ def _find_checkpoint(name: str, download_root: Optional[str]) -> Optional[str]:
     return None
 
 
+SYNTHETIC = "synthetic"
+_SYNTHETIC_ONLY = ("tiny-test",)      # test geometries: no checkpoint of them exists anywhere
+
+
 def load(name: str = "ViT-B/32", device: Union[str, torch.device] = "cuda", jit: bool = False,
          download_root: Optional[str] = None, weights: Union[None, str, Dict[str, torch.Tensor]] = None, seed: int = 0,
-         fold_ln: Optional[bool] = None):
+         fold_ln: Optional[bool] = None, pixel_dtype: Optional[torch.dtype] = None):
     """``clip.load`` signature.  Weights come from, in order: ``weights`` (a checkpoint path, or a state dict in
     OpenAI-CLIP, HF-CLIPModel or this package's naming -- checkpoint.py converts); a checkpoint file named by
-    ``name`` or found under ``download_root``; otherwise (nothing can be downloaded here) seeded synthetic
-    weights of the named architecture -- the same tensors the golden fixtures were produced with."""
+    ``name`` or found under ``download_root`` (the OpenAI package's cache layout, ``ViT-B-32.pt``).
+    Nothing can be downloaded here, so when none of these yields a file the call raises FileNotFoundError --
+    it does NOT silently hand back a model that encodes noise.  ``weights="synthetic"`` asks for that on
+    purpose: seeded random tensors of the named architecture (``seed``), the ones the golden fixtures, the
+    tests and bench.py use."""
     from . import checkpoint
 
-    path = weights if isinstance(weights, (str, os.PathLike)) else (_find_checkpoint(name, download_root) if weights is None else None)
+    synthetic = isinstance(weights, str) and weights == SYNTHETIC
+    if synthetic:
+        weights = None
+    path = weights if isinstance(weights, (str, os.PathLike)) else \
+        (_find_checkpoint(name, download_root) if weights is None and not synthetic else None)
     if path is not None:
         weights = checkpoint.read_state_dict(os.fspath(path))
     if weights is not None:
@@ -362,10 +438,20 @@ def load(name: str = "ViT-B/32", device: Union[str, torch.device] = "cuda", jit:
         if (cfg.vision, cfg.text) != (inferred.vision, inferred.text):
             raise ValueError(f"checkpoint geometry {inferred.vision} / {inferred.text} does not match {name}")
     else:
-        cfg = get_config(name)
+        cfg = get_config(name)            # unknown names raise here, as clip.load does
+        if not synthetic and name not in _SYNTHETIC_ONLY:
+            where = f" or under download_root={download_root!r}" if download_root else ""
+            raise FileNotFoundError(
+                f"no checkpoint for {name!r}: nothing at that path{where}, and this environment cannot download. "
+                f"Pass weights=<file or state dict> (OpenAI-clip / HF CLIPModel / safetensors), put "
+                f"{name.replace('/', '-').replace('@', '-')}.pt under download_root, or ask for random weights "
+                f"explicitly with weights={SYNTHETIC!r}.")
         weights = make_clip_weights(cfg, seed=seed)
     model = CLIP(cfg, weights, device, fold_ln=fold_ln)
-    return model, _preprocess_factory(cfg.vision.image_size, model.device)
+    model.synthetic_weights = path is None and synthetic or name in _SYNTHETIC_ONLY and path is None
+    preprocess = _preprocess_factory(cfg.vision.image_size, model.device, model, pixel_dtype)
+    model.processor = ClipProcessor(preprocess, cfg.text.tokens)
+    return model, preprocess
 
 
 _bpe_cache = {}

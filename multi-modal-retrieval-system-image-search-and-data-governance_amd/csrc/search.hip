@@ -725,7 +725,8 @@ __global__ __launch_bounds__(FIN_THREADS) void rescore_kernel(
 
 __global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
     int64_t N, int k, int ks, int tile_rows, const int32_t *__restrict__ sel_tiles, const double *__restrict__ cand,
-    const FinMeta *__restrict__ meta, float scale, float eps_coef, int32_t *__restrict__ idx,
+    const FinMeta *__restrict__ meta, float scale, float eps_rel, float host_bound,
+    const float *__restrict__ dev_bound, int32_t *__restrict__ idx,
     float *__restrict__ score, double *__restrict__ dot64, int32_t *__restrict__ status,
     int32_t *__restrict__ need_exact)
 {
@@ -753,8 +754,13 @@ __global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
     if (tid == 0) {
         // Certificate: every excluded tile's max (an fp32 MFMA dot) is <= bound; a row of an excluded
         // tile can only displace the k-th pick if its exact dot reaches kth, i.e. if bound + err >= kth.
+        // margin = eps_rel * ||q|| * (largest gallery row norm): the caller's bound and/or the one measured on the
+        // device (mmr_gallery_norm_bound); when both are given the larger one wins, so an understated caller bound
+        // cannot shrink the margin below what the data needs
         const double bound = (double)meta[qi].bound;
-        const double eps = (double)eps_coef * (double)meta[qi].qnorm;
+        float gnorm = host_bound;
+        if (dev_bound) gnorm = fmaxf(gnorm, *dev_bound);
+        const double eps = (double)eps_rel * (double)gnorm * (double)meta[qi].qnorm;
         const int kk = (int)(N < k ? N : k);
         const bool ok = (bound == -INFINITY) || (out_k[kk - 1] != KEY_NONE && out_v[kk - 1] > bound + eps);
         need_exact[qi] = ok ? 0 : 1;
@@ -943,6 +949,37 @@ __global__ __launch_bounds__(256) void l2norm_kernel(T *__restrict__ x, int64_t 
     }
 }
 
+// Largest row L2 norm of a gallery: sizes the certificate's margin (rank_kernel) from the data instead of from a
+// caller's promise.  One wave per row, 16-byte loads, grid-stride; each wave keeps its maximum of sum(x^2) and
+// lane 0 publishes sqrt(max) with one integer atomicMax (non-negative floats order like their bit patterns).
+// fp32 summation error (~E * 2^-24 relative) is far inside the margin's own headroom.  HBM-bound: one pass.
+template <typename T>
+__global__ __launch_bounds__(256) void rownorm_max_kernel(const T *__restrict__ gal, int64_t N, int E,
+                                                           unsigned int *__restrict__ out_bits)
+{
+    constexpr int VEC = 16 / sizeof(T);        // elements per 16-byte load
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int chunks = E / VEC;
+    float mx = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < N; r += (int64_t)gridDim.x * 4) {
+        const T *p = gal + (size_t)r * E;
+        float ss = 0.f;
+        for (int c = lane; c < chunks; c += 64) {
+            if constexpr (sizeof(T) == 2) {
+                const bf16x8 x = *reinterpret_cast<const bf16x8 *>(p + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float v = bf16_to_f32((bf16_t)x[j]); ss += v * v; }
+            } else {
+                const float4 x = *reinterpret_cast<const float4 *>(p + c * 4);
+                ss += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+            }
+        }
+        ss = wave_sum(ss);
+        mx = fmaxf(mx, ss);                    // NaN rows are skipped here like they are by the ranking
+    }
+    if (lane == 0) atomicMax(out_bits, __float_as_uint(sqrtf(mx) * 1.000001f));
+}
+
 __global__ void fill_empty_kernel(int32_t *idx, float *score, double *dot64, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1008,7 +1045,7 @@ struct SearchPlan {
     int ntiles, tpt, ntasks, nslab, ks, tile_rows, qmax;
     int64_t rows_per_slab;
     bool fast;  // MFMA scan usable
-    size_t off_bmax, off_tmax, off_flags, off_partial, off_seltiles, off_cand, off_meta, total;
+    size_t off_bmax, off_tmax, off_flags, off_partial, off_seltiles, off_cand, off_meta, off_nb, total;
 };
 
 static bool scan_supports_E(int E) { return E == 128 || E == 256 || E == 512 || E == 768; }
@@ -1048,6 +1085,7 @@ static SearchPlan make_plan(int64_t N, int E, int Q, int k, mmr_dtype dt)
     p.off_seltiles = off; off += align_up((size_t)qc * KS_MAX * sizeof(int32_t), 256);
     p.off_cand = off; off += align_up((size_t)qc * KS_MAX * TILE_ROWS * sizeof(double), 256);
     p.off_meta = off; off += align_up((size_t)qc * sizeof(FinMeta), 256);
+    p.off_nb = off; off += 256;            // measured gallery norm bound (one float) when the caller gives none
     p.total = off;
     return p;
 }
@@ -1091,7 +1129,8 @@ static int launch_scan_f32(const float *q, const float *gal, int Qc, int64_t N, 
 
 template <typename T, int PER>
 static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, const SearchPlan &p, int qpad,
-                           const float *bmax, const float *tmax, float scale, float eps_coef, int32_t *idx,
+                           const float *bmax, const float *tmax, float scale, float eps_rel, float host_bound,
+                           const float *dev_bound, int32_t *idx,
                            float *score, double *dot64, int32_t *status, int32_t *flags, int32_t *sel_tiles,
                            double *cand, FinMeta *meta, hipStream_t st)
 {
@@ -1103,7 +1142,7 @@ static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, c
                        cand, meta);
     MMR_CHECK_LAUNCH();
     hipLaunchKernelGGL(rank_kernel, dim3(Qc), dim3(FIN_THREADS), 0, st, N, k, p.ks, p.tile_rows, sel_tiles, cand, meta, scale,
-                       eps_coef,
+                       eps_rel, host_bound, dev_bound,
                        idx, score, dot64, status, flags);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
@@ -1145,16 +1184,37 @@ extern "C" size_t mmr_search_workspace_bytes(int64_t N, int E, int Q, int k)
     return a > b ? a : b;
 }
 
-extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
-                               float scale, float gallery_norm_bound, int32_t *idx, float *score, double *dot64,
-                               int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+static int launch_norm_bound(const void *gallery, mmr_dtype dtype, int64_t N, int E, float *out, hipStream_t st)
+{
+    MMR_CHECK_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+    if (N == 0) return MMR_OK;
+    const int64_t want = (N + 3) / 4;
+    const dim3 grid((unsigned)(want < 4096 ? want : 4096));
+    if (dtype == MMR_BF16) hipLaunchKernelGGL(rownorm_max_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t *)gallery, N, E, (unsigned int *)out);
+    else hipLaunchKernelGGL(rownorm_max_kernel<float>, grid, dim3(256), 0, st, (const float *)gallery, N, E, (unsigned int *)out);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+extern "C" int mmr_gallery_norm_bound(const void *gallery, mmr_dtype dtype, int64_t N, int E, float *bound_out, void *stream)
+{
+    MMR_CHECK_ARG(dtype == MMR_F32 || dtype == MMR_BF16, "mmr_gallery_norm_bound: dtype %d", (int)dtype);
+    MMR_CHECK_ARG(N >= 0 && E >= 8 && E % 8 == 0, "mmr_gallery_norm_bound: bad shape N=%lld E=%d (E must be a multiple of 8)", (long long)N, E);
+    MMR_CHECK_ARG(bound_out && (gallery || N == 0), "mmr_gallery_norm_bound: null pointer");
+    MMR_CHECK_ARG(((uintptr_t)gallery & 15) == 0, "mmr_gallery_norm_bound: gallery must be 16-byte aligned");
+    return launch_norm_bound(gallery, dtype, N, E, bound_out, (hipStream_t)stream);
+}
+
+static int cosine_topk_impl(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
+                            float scale, float gallery_norm_bound, const float *norm_bound_dev, int32_t *idx, float *score,
+                            double *dot64, int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
 {
     MMR_CHECK_ARG(dtype == MMR_F32 || dtype == MMR_BF16, "mmr_cosine_topk: dtype %d", (int)dtype);
     MMR_CHECK_ARG(Q >= 0 && N >= 0, "mmr_cosine_topk: negative size Q=%d N=%lld", Q, (long long)N);
     MMR_CHECK_ARG(N < 0x7fffffff, "mmr_cosine_topk: N=%lld exceeds int32 row ids (shard the gallery)", (long long)N);
     MMR_CHECK_ARG(k >= 1 && k <= K_MAX, "mmr_cosine_topk: k=%d outside [1,%d]", k, K_MAX);
     MMR_CHECK_ARG(scale > 0.f, "mmr_cosine_topk: scale must be > 0 (got %g)", (double)scale);
-    MMR_CHECK_ARG(gallery_norm_bound > 0.f, "mmr_cosine_topk: gallery_norm_bound must be > 0");
+    MMR_CHECK_ARG(gallery_norm_bound == gallery_norm_bound && gallery_norm_bound < INFINITY, "mmr_cosine_topk: gallery_norm_bound must be finite");
     if (!exact_supports_E(E)) { set_error("mmr_cosine_topk: E=%d unsupported (128,256,512,768,1024)", E); return MMR_ENOTSUP; }
     if (Q == 0) return MMR_OK;
     MMR_CHECK_ARG(q && idx && score && (gallery || N == 0), "mmr_cosine_topk: null pointer");
@@ -1181,7 +1241,17 @@ extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dty
         // fp32 MFMA accumulation error of a length-E dot is <= ~E*2^-24*|q||g| (bf16 x bf16 products are exact
         // in fp32; fp32 x fp32 products add one rounding each, same order); the margin below is that worst case
         // for E<=1024 with headroom.  It gates the fast path only.
-        const float eps_coef = 8e-5f * gallery_norm_bound;
+        const float eps_rel = 8e-5f;
+        float host_bound = gallery_norm_bound > 0.f ? gallery_norm_bound : 0.f;
+        const float *dev_bound = norm_bound_dev;
+        if (host_bound == 0.f && !dev_bound) {
+            // no bound from the caller: measure it (one extra pass over the gallery; GalleryIndex-style callers
+            // measure once with mmr_gallery_norm_bound and pass the device scalar instead)
+            float *nb = (float *)(ws + p.off_nb);
+            int rcn = launch_norm_bound(gallery, dtype, N, E, nb, st);
+            if (rcn != MMR_OK) return rcn;
+            dev_bound = nb;
+        }
         const int qmax = p.qmax;
         for (int q0 = 0; q0 < Q; q0 += qmax) {
             const int Qc = (Q - q0) < qmax ? (Q - q0) : qmax;
@@ -1211,14 +1281,14 @@ extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dty
             if (dtype == MMR_BF16) {
                 MMR_DISPATCH_PER(E, bf16_t, {
                     rc = launch_finalize<bf16_t, PER>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, k, p, qpad, bmax,
-                                                      tmax, scale, eps_coef, o_idx, o_score, o_dot, o_status, flags + q0,
+                                                      tmax, scale, eps_rel, host_bound, dev_bound, o_idx, o_score, o_dot, o_status, flags + q0,
                                                       (int32_t *)(ws + p.off_seltiles), (double *)(ws + p.off_cand),
                                                       (FinMeta *)(ws + p.off_meta), st);
                 });
             } else {
                 MMR_DISPATCH_PER(E, float, {
                     rc = launch_finalize<float, PER>((const float *)qc, (const float *)gallery, Qc, N, k, p, qpad, bmax, tmax,
-                                                     scale, eps_coef, o_idx, o_score, o_dot, o_status, flags + q0,
+                                                     scale, eps_rel, host_bound, dev_bound, o_idx, o_score, o_dot, o_status, flags + q0,
                                                      (int32_t *)(ws + p.off_seltiles), (double *)(ws + p.off_cand),
                                                      (FinMeta *)(ws + p.off_meta), st);
                 });
@@ -1257,6 +1327,23 @@ extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dty
         });
     }
     return rc;
+}
+
+extern "C" int mmr_cosine_topk(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
+                               float scale, float gallery_norm_bound, int32_t *idx, float *score, double *dot64,
+                               int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    return cosine_topk_impl(q, gallery, dtype, Q, N, E, k, scale, gallery_norm_bound, nullptr, idx, score, dot64, status,
+                            workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmr_cosine_topk_ex(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
+                                  float scale, float gallery_norm_bound, const float *gallery_norm_bound_dev, int32_t *idx,
+                                  float *score, double *dot64, int32_t *status, void *workspace, size_t workspace_bytes,
+                                  void *stream)
+{
+    return cosine_topk_impl(q, gallery, dtype, Q, N, E, k, scale, gallery_norm_bound, gallery_norm_bound_dev, idx, score,
+                            dot64, status, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mmr_similarity(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, float scale,

@@ -20,14 +20,14 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
 // vit_ops.hip
 int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P, int G, int K, int Kpad, hipStream_t st);
 int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h, int B, int T, int d, float eps, bf16_t *xb, float2 *stats, hipStream_t st);
-int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab, bf16_t *xb, float2 *stats, hipStream_t st);
+int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab, bf16_t *xb, float2 *stats, int32_t *status, hipStream_t st);
 int launch_layernorm(const float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps, hipStream_t st);
 int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const float *b, bf16_t *xc, int Nb, int T, int d, float eps, hipStream_t st);
 int launch_finish(const float *feat, void *out, mmr_dtype odt, int Nb, int E, int normalize, hipStream_t st);
-int launch_embed_bert(const int32_t *ids, const bf16_t *tok, const float *pos, const float *type0, const float *lw, const float *lb, float *h, bf16_t *x, int Nb, int T, int d, int vocab, float eps, hipStream_t st);
+int launch_embed_bert(const int32_t *ids, const bf16_t *tok, const float *pos, const float *type0, const float *lw, const float *lb, float *h, bf16_t *x, int Nb, int T, int d, int vocab, float eps, const int32_t *types, int32_t *status, hipStream_t st);
 int launch_layernorm_inplace(float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps, hipStream_t st);
 int launch_gather_first_rows(const bf16_t *x, bf16_t *xc, int Nb, int T, int d, hipStream_t st);
-int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, int causal, hipStream_t st);
+int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, int causal, const int32_t *kmask, hipStream_t st);
 
 static inline int round_up(int x, int a) { return (x + a - 1) / a * a; }
 
@@ -178,7 +178,7 @@ extern "C" void mmr_tower_destroy(mmr_tower *t) { delete t; }
 namespace {
 struct WsPlan {
     int M, Mpad, Mp, Mp_pad, Bpad;
-    size_t off_h, off_x, off_big, off_pe, off_xc, off_feat, off_xo, off_stats, total;
+    size_t off_status, off_h, off_x, off_big, off_pe, off_xc, off_feat, off_xo, off_stats, total;
 };
 WsPlan plan_ws(const mmr_tower_cfg &c, int B)
 {
@@ -197,6 +197,7 @@ WsPlan plan_ws(const mmr_tower_cfg &c, int B)
         const size_t ap = (size_t)p.Mp_pad * patch_kpad(c) * 2;
         if (ap > big) big = ap;
     }
+    put(p.off_status, 256);                                    // status word (include/mmr.h): always at offset 0
     put(p.off_h, (size_t)p.Mpad * d * 4);
     put(p.off_x, (size_t)p.Mpad * d * 2);
     put(p.off_big, big);
@@ -250,6 +251,8 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
     bf16_t *xo = fold ? (bf16_t *)(ws + p.off_xo) : x;
     float2 *stats = fold ? (float2 *)(ws + p.off_stats) : nullptr;
     bf16_t *xb = fold ? x : nullptr;
+    int32_t *status = (int32_t *)(ws + p.off_status);
+    MMR_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
 
     // ---- embeddings
     if (c.kind == 0) {
@@ -267,7 +270,7 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
                                       t->g<float>(MMR_P_LN_PRE_B), h, B, T, d, c.ln_eps, xb, stats, st))) return rc;
     } else {
         if ((rc = launch_embed_text((const int32_t *)input, t->g<bf16_t>(MMR_P_TOK_EMB), t->g<float>(MMR_P_POS), h, B, T, d,
-                                    c.vocab, xb, stats, st))) return rc;
+                                    c.vocab, xb, stats, status, st))) return rc;
     }
     if (tap && tap_after == -1) MMR_CHECK_HIP(hipMemcpyAsync(tap, h, hbytes, hipMemcpyDeviceToDevice, st));
 
@@ -278,7 +281,7 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
         a.stats_in = stats; a.stats_out = stats; a.xout = x; a.inv_d = 1.f / (float)d; a.eps = c.ln_eps;
         a.colsum = t->l<float>(MMR_P_QKV_C, i);
         if ((rc = launch_gemm_aux(EPI_LNFOLD_BF16, x, t->l<bf16_t>(MMR_P_QKV_W, i), p.Mpad, 3 * d, d, t->l<float>(MMR_P_QKV_B, i), big, a, st))) return rc;
-        if ((rc = launch_attention(big, xo, B, T, c.heads, d, c.kind == 1, st))) return rc;
+        if ((rc = launch_attention(big, xo, B, T, c.heads, d, c.kind == 1, nullptr, st))) return rc;
         if ((rc = launch_gemm_aux(EPI_RESID_STATS_F32, xo, t->l<bf16_t>(MMR_P_OUT_W, i), p.Mpad, d, d, t->l<float>(MMR_P_OUT_B, i), h, a, st))) return rc;
         a.colsum = t->l<float>(MMR_P_FC1_C, i);
         if ((rc = launch_gemm_aux(EPI_LNFOLD_GELU_BF16, x, t->l<bf16_t>(MMR_P_FC1_W, i), p.Mpad, m, d, t->l<float>(MMR_P_FC1_B, i), big, a, st))) return rc;
@@ -288,7 +291,7 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
     for (int i = 0; i < c.layers && !fold; ++i) {
         if ((rc = launch_layernorm(h, t->l<float>(MMR_P_LN1_W, i), t->l<float>(MMR_P_LN1_B, i), x, p.M, d, c.ln_eps, st))) return rc;
         if ((rc = launch_gemm(EPI_BIAS_BF16, x, t->l<bf16_t>(MMR_P_QKV_W, i), p.Mpad, 3 * d, d, t->l<float>(MMR_P_QKV_B, i), big, st))) return rc;
-        if ((rc = launch_attention(big, x, B, T, c.heads, d, c.kind == 1, st))) return rc;
+        if ((rc = launch_attention(big, x, B, T, c.heads, d, c.kind == 1, nullptr, st))) return rc;
         if ((rc = launch_gemm(EPI_BIAS_RESID_F32, x, t->l<bf16_t>(MMR_P_OUT_W, i), p.Mpad, d, d, t->l<float>(MMR_P_OUT_B, i), h, st))) return rc;
         if ((rc = launch_layernorm(h, t->l<float>(MMR_P_LN2_W, i), t->l<float>(MMR_P_LN2_B, i), x, p.M, d, c.ln_eps, st))) return rc;
         if ((rc = launch_gemm(EPI_BIAS_GELU_BF16, x, t->l<bf16_t>(MMR_P_FC1_W, i), p.Mpad, m, d, t->l<float>(MMR_P_FC1_B, i), big, st))) return rc;
@@ -322,7 +325,7 @@ extern "C" int mmr_text_encode(mmr_tower *t, const int32_t *ids, int N, void *ou
 namespace {
 struct BertWs {
     int M, Mpad, Npad;
-    size_t off_h, off_x, off_big, off_xc, off_xp, off_feat, total;
+    size_t off_status, off_h, off_x, off_big, off_xc, off_xp, off_feat, total;
 };
 BertWs plan_bert(const mmr_tower_cfg &c, int N, int T)
 {
@@ -334,6 +337,7 @@ BertWs plan_bert(const mmr_tower_cfg &c, int N, int T)
     const size_t wide = (size_t)(c.mlp > 3 * c.width ? c.mlp : 3 * c.width);
     size_t off = 0;
     auto put = [&](size_t &o, size_t bytes) { o = off; off += align_up(bytes, 256); };
+    put(p.off_status, 256);
     put(p.off_h, (size_t)p.Mpad * d * 4);
     put(p.off_x, (size_t)p.Mpad * d * 2);
     put(p.off_big, (size_t)p.Mpad * wide * 2);
@@ -351,9 +355,10 @@ extern "C" size_t mmr_bert_workspace_bytes(const mmr_tower *t, int N, int T)
     return plan_bert(t->cfg, N, T).total;
 }
 
-extern "C" int mmr_bert_forward(mmr_tower *t, const int32_t *ids, int N, int T, void *out, mmr_dtype out_dtype,
-                                int normalize, int tap_after, float *tap, void *workspace, size_t workspace_bytes,
-                                void *stream)
+extern "C" int mmr_bert_forward_masked(mmr_tower *t, const int32_t *ids, const int32_t *token_type_ids,
+                                       const int32_t *attention_mask, int N, int T, void *out, mmr_dtype out_dtype,
+                                       int normalize, int tap_after, float *tap, void *workspace, size_t workspace_bytes,
+                                       void *stream)
 {
     MMR_CHECK_ARG(t && t->cfg.kind == 2, "mmr_bert_forward: not a BERT tower");
     const mmr_tower_cfg &c = t->cfg;
@@ -379,13 +384,16 @@ extern "C" int mmr_bert_forward(mmr_tower *t, const int32_t *ids, int N, int T, 
     const size_t hbytes = (size_t)p.M * d * sizeof(float);
     int rc;
 
+    int32_t *status = (int32_t *)(ws + p.off_status);
+    MMR_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
     if ((rc = launch_embed_bert(ids, t->g<bf16_t>(MMR_P_TOK_EMB), t->g<float>(MMR_P_POS), t->g<float>(MMR_P_TYPE_EMB),
-                                t->g<float>(MMR_P_LN_PRE_W), t->g<float>(MMR_P_LN_PRE_B), h, x, N, T, d, c.vocab, c.ln_eps, st))) return rc;
+                                t->g<float>(MMR_P_LN_PRE_W), t->g<float>(MMR_P_LN_PRE_B), h, x, N, T, d, c.vocab, c.ln_eps,
+                                token_type_ids, status, st))) return rc;
     if (tap && tap_after == -1) MMR_CHECK_HIP(hipMemcpyAsync(tap, h, hbytes, hipMemcpyDeviceToDevice, st));
     // post-LN blocks (modeling_bert.py:139-204,282-352): x = LN(x + Attn(x)); x = LN(x + FFN(x))
     for (int i = 0; i < c.layers; ++i) {
         if ((rc = launch_gemm(EPI_BIAS_BF16, x, t->l<bf16_t>(MMR_P_QKV_W, i), p.Mpad, 3 * d, d, t->l<float>(MMR_P_QKV_B, i), big, st))) return rc;
-        if ((rc = launch_attention(big, x, N, T, c.heads, d, 0, st))) return rc;
+        if ((rc = launch_attention(big, x, N, T, c.heads, d, 0, attention_mask, st))) return rc;
         if ((rc = launch_gemm(EPI_BIAS_RESID_F32, x, t->l<bf16_t>(MMR_P_OUT_W, i), p.Mpad, d, d, t->l<float>(MMR_P_OUT_B, i), h, st))) return rc;
         if ((rc = launch_layernorm_inplace(h, t->l<float>(MMR_P_LN1_W, i), t->l<float>(MMR_P_LN1_B, i), x, p.M, d, c.ln_eps, st))) return rc;
         if ((rc = launch_gemm(EPI_BIAS_GELU_ERF_BF16, x, t->l<bf16_t>(MMR_P_FC1_W, i), p.Mpad, m, d, t->l<float>(MMR_P_FC1_B, i), big, st))) return rc;
@@ -398,6 +406,14 @@ extern "C" int mmr_bert_forward(mmr_tower *t, const int32_t *ids, int N, int T, 
     if ((rc = launch_gemm(EPI_BIAS_TANH_BF16, xc, t->g<bf16_t>(MMR_P_POOL_W), p.Npad, d, d, t->g<float>(MMR_P_POOL_B), xp, st))) return rc;
     if ((rc = launch_gemm(EPI_BIAS_F32, xp, t->g<bf16_t>(MMR_P_PROJ), p.Npad, E, d, t->g<float>(MMR_P_PROJ_B), feat, st))) return rc;
     return launch_finish(feat, out, out_dtype, N, E, normalize, st);
+}
+
+extern "C" int mmr_bert_forward(mmr_tower *t, const int32_t *ids, int N, int T, void *out, mmr_dtype out_dtype,
+                                int normalize, int tap_after, float *tap, void *workspace, size_t workspace_bytes,
+                                void *stream)
+{
+    return mmr_bert_forward_masked(t, ids, nullptr, nullptr, N, T, out, out_dtype, normalize, tap_after, tap, workspace,
+                                   workspace_bytes, stream);
 }
 
 // ---- kernel-level test hooks
@@ -419,5 +435,11 @@ extern "C" int mmr_debug_layernorm(const float *h, const float *w, const float *
 extern "C" int mmr_debug_attention(const void *qkv, void *o, int B, int T, int heads, int causal, void *stream)
 {
     MMR_CHECK_ARG(qkv && o && B >= 1 && B <= 65535 && T >= 1 && heads >= 1, "mmr_debug_attention: bad argument");
-    return launch_attention((const bf16_t *)qkv, (bf16_t *)o, B, T, heads, heads * 64, causal, (hipStream_t)stream);
+    return launch_attention((const bf16_t *)qkv, (bf16_t *)o, B, T, heads, heads * 64, causal, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mmr_debug_attention_masked(const void *qkv, void *o, int B, int T, int heads, const int32_t *key_mask, void *stream)
+{
+    MMR_CHECK_ARG(qkv && o && key_mask && B >= 1 && B <= 65535 && T >= 1 && heads >= 1, "mmr_debug_attention_masked: bad argument");
+    return launch_attention((const bf16_t *)qkv, (bf16_t *)o, B, T, heads, heads * 64, 0, key_mask, (hipStream_t)stream);
 }

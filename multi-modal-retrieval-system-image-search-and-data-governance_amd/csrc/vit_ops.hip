@@ -136,14 +136,17 @@ template <int VPL>
 __global__ __launch_bounds__(256) void embed_text_kernel(const int32_t *__restrict__ ids, const bf16_t *__restrict__ tok,
                                                          const float *__restrict__ pos, float *__restrict__ h, int Nb,
                                                          int T, int d, int vocab, bf16_t *__restrict__ xb,
-                                                         float2 *__restrict__ stats)
+                                                         float2 *__restrict__ stats, int32_t *__restrict__ status)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)Nb * T) return;
     const int t = (int)(row % T);
     int id = ids[row];
-    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // ids are validated on the host; clamp is a memory guard
+    // out-of-range ids: clamped (memory guard) and reported through the workspace's status word -- the host does
+    // not read ids that already live on the GPU (that would be a sync per call)
+    if ((id < 0 || id >= vocab) && lane == 0) atomicOr(status, 1);
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
     float x[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
@@ -178,20 +181,25 @@ __global__ __launch_bounds__(256) void embed_bert_kernel(const int32_t *__restri
                                                          const float *__restrict__ pos, const float *__restrict__ type0,
                                                          const float *__restrict__ lw, const float *__restrict__ lb,
                                                          float *__restrict__ h, bf16_t *__restrict__ x, int Nb, int T,
-                                                         int d, int vocab, float eps)
+                                                         int d, int vocab, float eps, const int32_t *__restrict__ types,
+                                                         int32_t *__restrict__ status)
 {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)Nb * T) return;
     const int t = (int)(row % T);
     int id = ids[row];
+    int ty = types ? types[row] : 0;                       // token_type_ids (segment 0 / 1); absent = all zero
+    if ((id < 0 || id >= vocab || ty < 0 || ty > 1) && lane == 0) atomicOr(status, 1);
     id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+    ty = ty < 0 ? 0 : (ty > 1 ? 1 : ty);
+    const float *typ = type0 + (size_t)ty * d;
     float v[VPL];
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         const int col = j * 64 + lane;
         // same association as HF: (word + type) + position
-        v[j] = (bf16_to_f32(tok[(size_t)id * d + col]) + type0[col]) + pos[(size_t)t * d + col];
+        v[j] = (bf16_to_f32(tok[(size_t)id * d + col]) + typ[col]) + pos[(size_t)t * d + col];
     }
     ln_row<VPL>(v, lw, lb, lane, d, eps);
 #pragma unroll
@@ -323,14 +331,18 @@ __device__ __forceinline__ float quad_rows_reduce(float v, F op) {
 //   S^T = K.Q^T (keys on the MFMA row axis, so the softmax reduction over keys is mostly in-lane
 //   and the bf16 P tile is already the B operand of the P.V product), softmax fp32, O^T = V^T.P^T.
 // ---------------------------------------------------------------------------------------------
-template <int NT, bool CAUSAL>
+//   MASKED: a key-padding mask kmask[B,T] (int32, non-zero = attend), HF's `attention_mask` for padded text batches
+//   (BERT text tower): masked keys get weight 0.  A sequence whose keys are ALL masked yields zeros (HF would
+//   yield the mean of V; no caller produces such a row).
+template <int NT, bool CAUSAL, bool MASKED>
 __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o, int T,
-                                                        int d, float scale)
+                                                        int d, float scale, const int32_t *__restrict__ kmask)
 {
     constexpr int TPAD = NT * 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *Ks = smem;                    // [TPAD][64] bf16, 16-B chunks XOR-swizzled by (row & 7)
     char *Vs = smem + TPAD * 128;       // same image for V; read column-wise with ds_read_b64_tr_b16
+    int32_t *Ms = reinterpret_cast<int32_t *>(smem + 2 * TPAD * 128);   // MASKED: [TPAD] key mask of this sequence
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = blockIdx.x, b = blockIdx.y;
@@ -361,6 +373,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         }
         *reinterpret_cast<uint4 *>(Ks + row * 128 + ((c ^ (row & 7)) << 4)) = kk;
         *reinterpret_cast<uint4 *>(Vs + row * 128 + ((c ^ (row & 7)) << 4)) = vv;
+    }
+    if constexpr (MASKED) {
+        for (int i = tid; i < TPAD; i += 256) Ms[i] = i < T ? kmask[(size_t)b * T + i] : 0;
     }
     __syncthreads();
 
@@ -396,13 +411,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         // sc[jt][r] = S[query qi][key jt*16 + 4*fg + r]
         float mx = -INFINITY;
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt) {
+            int4 mk = make_int4(1, 1, 1, 1);
+            if constexpr (MASKED) mk = *reinterpret_cast<const int4 *>(Ms + jt * 16 + fg * 4);
+            const int mkr[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = jt * 16 + fg * 4 + r;
-                if (key >= T || (CAUSAL && key > qi)) sc[jt][r] = -INFINITY;
+                if (key >= T || (CAUSAL && key > qi) || (MASKED && mkr[r] == 0)) sc[jt][r] = -INFINITY;
                 mx = fmaxf(mx, sc[jt][r]);
             }
+        }
         mx = quad_rows_reduce(mx, [](float p, float q) { return fmaxf(p, q); });
         const float m2 = mx == -INFINITY ? 0.f : mx * c2;      // scale > 0: max commutes with the scaling
         float sum = 0.f;
@@ -415,7 +434,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
                 sum += p;
             }
         sum = quad_rows_reduce(sum, [](float p, float q) { return p + q; });
-        const float inv = 1.f / sum;
+        const float inv = (MASKED && sum == 0.f) ? 0.f : 1.f / sum;
 
         // the transposed reads are invisible to the compiler's counters: wait, then re-define the raw registers here so
         // no copy into the MFMA operand tuples can be scheduled before the data has landed
@@ -477,11 +496,13 @@ constexpr int ABUF = 2 * AIMG;                // one buffer: K image + V image
 // QB = 16-query blocks per wave (1 or 2).  With QB = 2 every K row fragment and every transposed V read feeds two
 // MFMAs, which halves the LDS bytes per FLOP -- the limiter at QB = 1, where each wave re-reads the whole 16 KiB
 // K/V block for 16 queries -- at the price of 128-query workgroups (more padding when T mod 128 is small).
-template <bool CAUSAL, int QB>
+// MASKED: key-padding mask as in attention_kernel; the block's 64 mask words ride in a small LDS array per buffer.
+template <bool CAUSAL, int QB, bool MASKED>
 __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__restrict__ qkv, bf16_t *__restrict__ o,
-                                                               int T, int d, float scale)
+                                                               int T, int d, float scale, const int32_t *__restrict__ kmask)
 {
-    __shared__ __attribute__((aligned(16))) char smem[2 * ABUF];
+    __shared__ __attribute__((aligned(16))) char smem[2 * ABUF + (MASKED ? 2 * AKB * 4 : 0)];
+    int32_t *Ms = reinterpret_cast<int32_t *>(smem + 2 * ABUF);     // MASKED: [2][AKB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hd = blockIdx.y, b = blockIdx.z;
     const size_t ld = (size_t)3 * d;
@@ -502,7 +523,12 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
 
     // each thread moves 2 K chunks and 2 V chunks (16 B each) per key block
     uint4 kreg[2], vreg[2];
+    int32_t mreg = 0;
     auto gload = [&](int kb) {
+        if constexpr (MASKED) {
+            const int key = kb * AKB + tid;
+            mreg = (tid < AKB && key < T) ? kmask[(size_t)b * T + key] : 0;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + i * 256, row = id >> 3, c = id & 7, key = kb * AKB + row;
@@ -516,6 +542,7 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
     };
     auto lwrite = [&](int buf) {
         char *Ks = smem + buf * ABUF, *Vs = Ks + AIMG;
+        if constexpr (MASKED) { if (tid < AKB) Ms[buf * AKB + tid] = mreg; }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + i * 256, row = id >> 3, c = id & 7;
@@ -576,16 +603,20 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
                 vraw[s2][dt][1] = lds_read_tr16(Vs + (r0 + 16) * 128 + ch + 8 * (tp & 1));
             }
         // keys past T (last block only) and, for the causal form, keys after the query
-        if (CAUSAL || kb == nkb - 1) {
+        if (CAUSAL || MASKED || kb == nkb - 1) {
 #pragma unroll
-            for (int x = 0; x < QB; ++x)
+            for (int jt = 0; jt < 4; ++jt) {
+                int4 mk = make_int4(1, 1, 1, 1);
+                if constexpr (MASKED) mk = *reinterpret_cast<const int4 *>(Ms + buf * AKB + jt * 16 + fg * 4);
+                const int mkr[4] = {mk.x, mk.y, mk.z, mk.w};
 #pragma unroll
-                for (int jt = 0; jt < 4; ++jt)
+                for (int x = 0; x < QB; ++x)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = kb * AKB + jt * 16 + fg * 4 + r;
-                        if (key >= T || (CAUSAL && key > q0 + 16 * x)) sc[x][jt][r] = -INFINITY;
+                        if (key >= T || (CAUSAL && key > q0 + 16 * x) || (MASKED && mkr[r] == 0)) sc[x][jt][r] = -INFINITY;
                     }
+            }
         }
         bool moved = false;
         float alpha[QB];
@@ -657,7 +688,7 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
         const float lx = quad_rows_reduce(l[x], [](float p, float q) { return p + q; });
-        const float inv = 1.f / lx;
+        const float inv = (MASKED && lx == 0.f) ? 0.f : 1.f / lx;
         const int qi = q0 + 16 * x;
         if (qi < T) {
             bf16_t *dst = o + ((size_t)b * T + qi) * d + hd * 64 + fg * 4;
@@ -706,11 +737,11 @@ int launch_embed_vision(const float *pe, const float *cls, const float *pos, con
 }
 
 int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab,
-                      bf16_t *xb, float2 *stats, hipStream_t st)
+                      bf16_t *xb, float2 *stats, int32_t *status, hipStream_t st)
 {
     ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)(((int64_t)Nb * T + 3) / 4));
-    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_text_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, h, Nb, T, d, vocab, xb, stats));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_text_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, h, Nb, T, d, vocab, xb, stats, status));
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
@@ -736,11 +767,12 @@ int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const flo
 }
 
 int launch_embed_bert(const int32_t *ids, const bf16_t *tok, const float *pos, const float *type0, const float *lw,
-                      const float *lb, float *h, bf16_t *x, int Nb, int T, int d, int vocab, float eps, hipStream_t st)
+                      const float *lb, float *h, bf16_t *x, int Nb, int T, int d, int vocab, float eps, const int32_t *types,
+                      int32_t *status, hipStream_t st)
 {
     ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)(((int64_t)Nb * T + 3) / 4));
-    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_bert_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, type0, lw, lb, h, x, Nb, T, d, vocab, eps));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_bert_kernel<VPL>, grid, dim3(256), 0, st, ids, tok, pos, type0, lw, lb, h, x, Nb, T, d, vocab, eps, types, status));
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
@@ -774,24 +806,26 @@ int launch_finish(const float *feat, void *out, mmr_dtype odt, int Nb, int E, in
     return MMR_OK;
 }
 
-template <int NT, bool CAUSAL>
-static int launch_attention_t(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, hipStream_t st)
+template <int NT, bool CAUSAL, bool MASKED>
+static int launch_attention_t(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, const int32_t *kmask, hipStream_t st)
 {
     ProfScope prof(MMR_PROF_ATTENTION, st);
     constexpr int TPAD = NT * 16;
-    constexpr int lds = 2 * TPAD * 128;          // K image + V image
+    constexpr int lds = 2 * TPAD * 128 + (MASKED ? TPAD * 4 : 0);          // K image + V image (+ key mask)
     static DeviceOnce once;
     if (once.first()) {
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<NT, CAUSAL>),
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&attention_kernel<NT, CAUSAL, MASKED>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
-    hipLaunchKernelGGL((attention_kernel<NT, CAUSAL>), dim3(heads, Bn), dim3(256), lds, st, qkv, o, T, d, 0.125f);
+    hipLaunchKernelGGL((attention_kernel<NT, CAUSAL, MASKED>), dim3(heads, Bn), dim3(256), lds, st, qkv, o, T, d, 0.125f, kmask);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
 
-int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, int causal, hipStream_t st)
+// kmask: nullable key-padding mask [Bn,T] int32 (non-zero = attend); only the non-causal (BERT) form takes one
+int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int d, int causal, const int32_t *kmask, hipStream_t st)
 {
+    if (kmask && causal) { set_error("attention: a key mask with the causal form is not built"); return MMR_ENOTSUP; }
     const int nt = (T + 31) / 32 * 2;
     if (nt > 6) {   // long sequences: streaming kernel
         ProfScope prof(MMR_PROF_ATTENTION, st);
@@ -801,26 +835,35 @@ int launch_attention(const bf16_t *qkv, bf16_t *o, int Bn, int T, int heads, int
         const int qb = force_qb ? force_qb : (pad128 == pad64 ? 2 : 1);
         const dim3 grid(qb == 2 ? pad128 / 128 : pad64 / 64, heads, Bn);
         if (causal) {
-            if (qb == 2) hipLaunchKernelGGL((attention_stream_kernel<true, 2>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
-            else hipLaunchKernelGGL((attention_stream_kernel<true, 1>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+            if (qb == 2) hipLaunchKernelGGL((attention_stream_kernel<true, 2, false>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f, nullptr);
+            else hipLaunchKernelGGL((attention_stream_kernel<true, 1, false>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f, nullptr);
+        } else if (kmask) {
+            if (qb == 2) hipLaunchKernelGGL((attention_stream_kernel<false, 2, true>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f, kmask);
+            else hipLaunchKernelGGL((attention_stream_kernel<false, 1, true>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f, kmask);
         } else {
-            if (qb == 2) hipLaunchKernelGGL((attention_stream_kernel<false, 2>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
-            else hipLaunchKernelGGL((attention_stream_kernel<false, 1>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f);
+            if (qb == 2) hipLaunchKernelGGL((attention_stream_kernel<false, 2, false>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f, nullptr);
+            else hipLaunchKernelGGL((attention_stream_kernel<false, 1, false>), grid, dim3(256), 0, st, qkv, o, T, d, 0.125f, nullptr);
         }
         MMR_CHECK_LAUNCH();
         return MMR_OK;
     }
-    if (!causal) {
+    if (kmask) {
         switch (nt) {
-            case 2: return launch_attention_t<2, false>(qkv, o, Bn, T, heads, d, st);
-            case 4: return launch_attention_t<4, false>(qkv, o, Bn, T, heads, d, st);
-            case 6: return launch_attention_t<6, false>(qkv, o, Bn, T, heads, d, st);
+            case 2: return launch_attention_t<2, false, true>(qkv, o, Bn, T, heads, d, kmask, st);
+            case 4: return launch_attention_t<4, false, true>(qkv, o, Bn, T, heads, d, kmask, st);
+            case 6: return launch_attention_t<6, false, true>(qkv, o, Bn, T, heads, d, kmask, st);
+        }
+    } else if (!causal) {
+        switch (nt) {
+            case 2: return launch_attention_t<2, false, false>(qkv, o, Bn, T, heads, d, nullptr, st);
+            case 4: return launch_attention_t<4, false, false>(qkv, o, Bn, T, heads, d, nullptr, st);
+            case 6: return launch_attention_t<6, false, false>(qkv, o, Bn, T, heads, d, nullptr, st);
         }
     } else {
         switch (nt) {
-            case 2: return launch_attention_t<2, true>(qkv, o, Bn, T, heads, d, st);
-            case 4: return launch_attention_t<4, true>(qkv, o, Bn, T, heads, d, st);
-            case 6: return launch_attention_t<6, true>(qkv, o, Bn, T, heads, d, st);
+            case 2: return launch_attention_t<2, true, false>(qkv, o, Bn, T, heads, d, nullptr, st);
+            case 4: return launch_attention_t<4, true, false>(qkv, o, Bn, T, heads, d, nullptr, st);
+            case 6: return launch_attention_t<6, true, false>(qkv, o, Bn, T, heads, d, nullptr, st);
         }
     }
     set_error("attention: %d tokens (%s) has no kernel instance", T, causal ? "causal" : "full");

@@ -103,7 +103,22 @@ def tip_adapter_logits(features: torch.Tensor, clip_weights: torch.Tensor, cache
     return (tip, clip) if return_clip_logits else tip
 
 
-def _local_topk(q, g, k, scale, norm_bound, want_dot64, want_status, workspace=None):
+def gallery_norm_bound(gallery: torch.Tensor) -> torch.Tensor:
+    """Largest row L2 norm of ``gallery`` as a 1-element fp32 DEVICE tensor (no host sync): what sizes the
+    margin of the fast path's exactness certificate.  One HBM-bound pass."""
+    if not gallery.is_cuda:
+        raise RuntimeError("gallery must live on the GPU (there is no CPU path)")
+    g = gallery.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=g.device)
+    L = _lib.lib()
+    _lib.check(L.mmr_gallery_norm_bound(g.data_ptr(), _lib.dtype_code(g.dtype), g.shape[0], g.shape[1], out.data_ptr(),
+                                        _lib.stream_ptr(g.device)))
+    return out
+
+
+def _local_topk(q, g, k, scale, norm_bound, want_dot64, want_status, workspace=None, norm_bound_dev=None):
+    """norm_bound: caller's bound (None / <= 0: none); norm_bound_dev: measured device scalar (None: none).
+    Neither given -> the C call measures the gallery itself."""
     Q, E = q.shape
     N = g.shape[0]
     dev = g.device
@@ -115,14 +130,17 @@ def _local_topk(q, g, k, scale, norm_bound, want_dot64, want_status, workspace=N
     score = torch.empty(Q, k, dtype=torch.float32, device=dev)
     dot64 = torch.empty(Q, k, dtype=torch.float64, device=dev) if want_dot64 else None
     status = torch.empty(Q, dtype=torch.int32, device=dev) if want_status else None
-    _lib.check(L.mmr_cosine_topk(q.data_ptr(), g.data_ptr(), _lib.dtype_code(g.dtype), Q, N, E, k, float(scale),
-                                 float(norm_bound), idx.data_ptr(), score.data_ptr(), _lib.ptr(dot64),
-                                 _lib.ptr(status), workspace.data_ptr(), workspace.numel(), _lib.stream_ptr(dev)))
+    nb = 0.0 if norm_bound is None else float(norm_bound)
+    if nb != nb or nb == float("inf"):
+        raise ValueError("gallery_norm_bound must be finite")
+    _lib.check(L.mmr_cosine_topk_ex(q.data_ptr(), g.data_ptr(), _lib.dtype_code(g.dtype), Q, N, E, k, float(scale),
+                                    nb, _lib.ptr(norm_bound_dev), idx.data_ptr(), score.data_ptr(), _lib.ptr(dot64),
+                                    _lib.ptr(status), workspace.data_ptr(), workspace.numel(), _lib.stream_ptr(dev)))
     return idx, score, dot64, status, workspace
 
 
 def cosine_topk(queries: torch.Tensor, gallery: torch.Tensor, k: int = 10, scale: float = 1.0,
-                gallery_norm_bound: float = 1.0, return_dot64: bool = False, return_status: bool = False):
+                gallery_norm_bound: Optional[float] = None, return_dot64: bool = False, return_status: bool = False):
     """Top-k gallery rows per query, like ``(scale * queries @ gallery.t()).topk(k, 1, True, True)``.
 
     Returns ``(values fp32 [Q,k], indices int64 [Q,k])`` -- torch.topk's order of results -- plus
@@ -130,6 +148,10 @@ def cosine_topk(queries: torch.Tensor, gallery: torch.Tensor, k: int = 10, scale
     (-dot, +row index) on fp64 dot products, so ties go to the lowest row id (torch's CPU tie
     order is unspecified) and indices are bit-reproducible against oracle/search_ref.c.
     Empty slots (k > N) hold index -1 / score -inf.
+
+    ``gallery_norm_bound`` (an upper bound on any row's L2 norm) sizes the certificate of the fast path.
+    Left at None it is MEASURED from the gallery in the same call (one extra streaming pass; a
+    ``GalleryIndex`` measures once); a caller who passes a number promises it holds (include/mmr.h).
     """
     q2, squeezed = _as_2d(queries)
     q, g = _prep_pair(q2, gallery)
@@ -167,35 +189,64 @@ class GalleryIndex:
     """A device-resident embedding matrix [N,E] with a reusable search workspace.
 
     Stands where the reference keeps ``test_features`` (code/search_image.py:167-182) and
-    scores it against reference vectors; rows are whatever ``encode_image`` produced.
+    scores it against reference vectors; rows are whatever ``encode_image`` produced -- normalised or
+    not: the largest row norm is measured once here (device scalar, no host sync) and sizes the
+    certificate's margin; a caller-supplied ``norm_bound`` can only widen it.
     """
 
-    def __init__(self, gallery: torch.Tensor, norm_bound: float = 1.0):
+    def __init__(self, gallery: torch.Tensor, norm_bound: Optional[float] = None):
         if not gallery.is_cuda:
             raise RuntimeError("GalleryIndex needs a CUDA/HIP tensor")
         if gallery.dtype not in (torch.float32, torch.bfloat16):
             gallery = gallery.float()
         self.gallery = gallery.contiguous()
-        self.norm_bound = float(norm_bound)
+        self.norm_bound = None if norm_bound is None else float(norm_bound)
+        self.norm_bound_dev = gallery_norm_bound(self.gallery)
         self._ws = None
 
     @property
     def num_rows(self) -> int:
         return self.gallery.shape[0]
 
-    def search(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0, return_dot64: bool = False):
+    def search(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0, return_dot64: bool = False,
+               return_status: bool = False):
         q2, squeezed = _as_2d(queries)
         q = q2.to(device=self.gallery.device, dtype=self.gallery.dtype).contiguous()
-        idx, score, dot64, _, self._ws = _local_topk(q, self.gallery, int(k), scale, self.norm_bound,
-                                                     return_dot64, False, self._ws)
+        idx, score, dot64, status, self._ws = _local_topk(q, self.gallery, int(k), scale, self.norm_bound,
+                                                          return_dot64, return_status, self._ws, self.norm_bound_dev)
         idx = idx.to(torch.int64)
         if squeezed:
             idx, score = idx[0], score[0]
-        return (score, idx, dot64) if return_dot64 else (score, idx)
+            dot64 = dot64[0] if dot64 is not None else None
+        out = (score, idx)
+        if return_dot64:
+            out = out + (dot64,)
+        if return_status:
+            out = out + (status,)
+        return out
 
     def scores(self, ref_feature: torch.Tensor, scale: float = 100.0) -> torch.Tensor:
         """``get_similarity``'s first line for this gallery (reference code/search_image.py:107)."""
         return similarity(self.gallery, ref_feature, scale)
+
+
+class _PendingSearch:
+    """One query batch of a ShardedGalleryIndex whose all-gather is in flight."""
+
+    def __init__(self, owner, gathered, work, scale, squeezed):
+        self.owner, self.gathered, self.work, self.scale, self.squeezed = owner, gathered, work, scale, squeezed
+
+    def result(self, return_dot64: bool = False):
+        """(values fp32 [Q,k], global int64 ids [Q,k] [, exact fp64 dots]); stream-ordered behind the collective."""
+        if self.work is not None:
+            self.work.wait()          # nccl: the CURRENT STREAM waits for the collective, the host does not
+            self.work = None
+        idx_parts = self.gathered[..., 0].contiguous()
+        dot_parts = self.gathered[..., 1].contiguous().view(torch.float64)
+        out = self.owner._merge(idx_parts, dot_parts, self.scale)       # (score, idx, dot64)
+        if self.squeezed:
+            out = tuple(t[0] for t in out)
+        return out if return_dot64 else out[:2]
 
 
 class ShardedGalleryIndex:
@@ -204,11 +255,16 @@ class ShardedGalleryIndex:
     exact merge.  Global top-k is a subset of the union of local top-k lists, so the merged result
     equals the single-GPU result bit for bit.
 
+    ``search`` is one batch, start to finish.  ``search_async`` returns as soon as the batch's collective
+    is issued (``all_gather_into_tensor(async_op=True)``: it runs on the backend's own stream), so the next
+    batch's gallery scan -- or the caller's next encode -- overlaps it; ``.result()`` makes the current
+    stream wait for the collective and merges.  ``search_pipelined`` does that over a list of batches.
+
     ``local_search`` / ``merge`` exist so the collective and offset logic can be exercised on a
     CPU ``gloo`` group in tests; the defaults are the HIP kernels.
     """
 
-    def __init__(self, local_gallery: torch.Tensor, group=None, norm_bound: float = 1.0,
+    def __init__(self, local_gallery: torch.Tensor, group=None, norm_bound: Optional[float] = None,
                  local_search: Optional[Callable] = None, merge: Optional[Callable] = None):
         import torch.distributed as dist
 
@@ -223,9 +279,8 @@ class ShardedGalleryIndex:
         self._merge = merge or merge_topk
         n_local = torch.tensor([local_gallery.shape[0]], dtype=torch.int64, device=local_gallery.device)
         if self.use_dist:
-            counts = [torch.zeros_like(n_local) for _ in range(self.world)]
-            dist.all_gather(counts, n_local, group=group)
-            counts = torch.cat(counts)
+            counts = torch.empty(self.world, dtype=torch.int64, device=local_gallery.device)
+            dist.all_gather_into_tensor(counts, n_local, group=group)
         else:
             counts = n_local
         self.counts = counts.cpu()
@@ -233,22 +288,43 @@ class ShardedGalleryIndex:
         self.offset = int(self.offsets[self.rank])
         self.total_rows = int(self.counts.sum())
 
-    def search(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0):
-        """Every rank passes the same queries; every rank gets the same global (values, int64 ids)."""
+    def local_topk(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0):
+        """This rank's (global int64 ids [Q,k], fp64 dots [Q,k]) -- the payload of the collective."""
+        q2, _ = _as_2d(queries)
         if self._local_search is None:
-            _, lidx, ldot = self._index.search(queries, k, scale, return_dot64=True)
+            _, lidx, ldot = self._index.search(q2, k, scale, return_dot64=True)
         else:
-            lidx, ldot = self._local_search(queries, self.local, k)
+            lidx, ldot = self._local_search(q2, self.local, k)
         gidx = torch.where(lidx >= 0, lidx.to(torch.int64) + self.offset, lidx.to(torch.int64))
+        return gidx, ldot
+
+    def search_async(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0) -> _PendingSearch:
+        squeezed = queries.dim() == 1
+        gidx, ldot = self.local_topk(queries, k, scale)
         # one packed message per rank: [Q,k,2] int64 = (global id, fp64 dot bits)
         packed = torch.stack([gidx, ldot.view(torch.int64)], dim=-1).contiguous()
         if self.use_dist:
-            parts = [torch.empty_like(packed) for _ in range(self.world)]
-            self.dist.all_gather(parts, packed, group=self.group)     # the one collective of the search path
-            gathered = torch.stack(parts)
+            # output = the ranks' messages concatenated along dim 0 (the layout both nccl and gloo accept)
+            flat = torch.empty((self.world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype,
+                               device=packed.device)
+            work = self.dist.all_gather_into_tensor(flat, packed, group=self.group, async_op=True)   # THE collective
+            gathered = flat.view((self.world,) + tuple(packed.shape))
         else:
-            gathered = packed.unsqueeze(0)
-        idx_parts = gathered[..., 0].contiguous()
-        dot_parts = gathered[..., 1].contiguous().view(torch.float64)
-        score, idx, _ = self._merge(idx_parts, dot_parts, scale)
-        return score, idx
+            gathered, work = packed.unsqueeze(0), None
+        return _PendingSearch(self, gathered, work, scale, squeezed)
+
+    def search(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0):
+        """Every rank passes the same queries; every rank gets the same global (values, int64 ids)."""
+        return self.search_async(queries, k, scale).result()
+
+    def search_pipelined(self, batches, k: int = 10, scale: float = 1.0):
+        """[(values, ids)] for a sequence of query batches: batch i's all-gather overlaps batch i+1's scan."""
+        out, pending = [], None
+        for qb in batches:
+            nxt = self.search_async(qb, k, scale)
+            if pending is not None:
+                out.append(pending.result())
+            pending = nxt
+        if pending is not None:
+            out.append(pending.result())
+        return out

@@ -164,6 +164,17 @@ def bert_golden(name, n_txt, T, with_stages):
     print(f"[{name}] BERT logits oracle-vs-HF max|diff| = {d:.3e} (|f|~{float(out_hf.logits.norm(dim=-1).mean()):.2f})")
     assert d <= 5e-5 * max(1.0, float(out_hf.logits.abs().max())), d
     out = {"weight_seed": 0, "ids_seed": 7, "n_txt": n_txt, "T": T, "logits": out_hf.logits.numpy()}
+    # the tokenizer-output form (reference CLIP/union_dataset.py:312-314): padded keys masked, some type-1 tokens
+    mask = (ids != 0).long()
+    types = torch.zeros_like(ids).long()
+    types[:, T // 2:] = 1
+    types = types * mask
+    out_m = hf(input_ids=ids.long(), attention_mask=mask, token_type_ids=types).logits
+    or_m = bert_ref.bert_logits(w, cfg, ids, attention_mask=mask, token_type_ids=types)
+    dm = _maxdiff(out_m, or_m)
+    print(f"[{name}] BERT masked logits oracle-vs-HF max|diff| = {dm:.3e}; masked-vs-unmasked {_maxdiff(out_m, out_hf.logits):.3e}")
+    assert dm <= 5e-5 * max(1.0, float(out_m.abs().max())), dm
+    out["logits_masked"] = out_m.numpy()
     if with_stages:
         hs = hf.bert(ids.long(), output_hidden_states=True).hidden_states
         assert _maxdiff(hs[0], st["embed"]) <= 2e-5 and _maxdiff(hs[1], st["layer0"]) <= 5e-5

@@ -2,7 +2,9 @@
 
 Tolerances (stated per BASELINE.json north_star: "cosine scores within 1e-3 bf16 tolerance"):
   * kernel unit tests compare against a torch fp32 computation on the SAME bf16-rounded inputs;
-  * tower features: cosine(feature_gpu, feature_oracle) >= 1 - 1e-3 and |cos scores diff| <= 1e-3.
+  * tower features: cosine(feature_gpu, feature_oracle) >= 1 - 1e-3 and |cos scores diff| <= 1e-3 -- the CONTRACT;
+  * next to it every tower check asserts a regression GUARD of about three times what the kernels actually
+    measure (`_check_cos`): the contract is a ceiling a change could lose 30x accuracy under and stay green.
 Weights are bf16-representable by construction, so oracle and device consume identical values.
 """
 import os
@@ -26,6 +28,19 @@ def L(device):
 def _cos(a, b):
     a, b = a.double(), b.double()
     return (a * b).sum(-1) / (a.norm(dim=-1) * b.norm(dim=-1))
+
+
+COS_CONTRACT = 1e-3     # BASELINE.json north_star: "cosine scores within 1e-3 bf16 tolerance"
+COS_GUARD = 3e-5        # ~3x the largest 1 - cos measured on MI355X over every tower / geometry tested here (1e-5)
+COS_GUARD_FOLD = 1e-4   # folded-LayerNorm towers round h instead of LN(h) to bf16: ~3x their measured 3e-5
+
+
+def _check_cos(got, want, what, fold=False):
+    c = 1.0 - _cos(got, want).min().item()
+    guard = COS_GUARD_FOLD if fold else COS_GUARD
+    assert c <= COS_CONTRACT, f"{what}: 1 - cos = {c:.2e} breaks the 1e-3 contract"
+    assert c <= guard, f"{what}: 1 - cos = {c:.2e} is inside the contract but above the regression guard {guard:.0e}"
+    return c
 
 
 # ------------------------------------------------------------------ kernel-level
@@ -57,25 +72,29 @@ def test_gemm_epilogues(L, device, M, N, K, epi):
         ref = torch.tanh(ref)                                 # BERT pooler
     Ad, Wd, bd = A.to(device), W.to(device), bias.to(device)
     st = L.stream_ptr(device)
+    # Guards sized from what the kernels measure (x3), not from the 1e-3 contract: a bf16 output is the fp32 result rounded
+    # once (half an ulp = 2^-9 relative; the bound below allows a whole ulp, 2^-8) plus fp32 accumulation noise that both
+    # the MFMA and the CPU reference carry (~1e-6 of the largest output for K <= 3072); fp32 outputs carry only the latter.
+    scale = max(1.0, ref.abs().max().item())
     if epi in (0, 1, 5, 6):
         out = torch.empty(M, N, dtype=torch.bfloat16, device=device)
         L.check(L.lib().mmr_debug_gemm(epi, Ad.data_ptr(), Wd.data_ptr(), M, N, K, bd.data_ptr(), out.data_ptr(), st))
         got = out.float().cpu()
-        tol = 1e-2 * ref.abs().max().item() + 1e-3           # bf16 output rounding
+        bound = 2.0 ** -8 * ref.abs() + 2e-5 * scale
     elif epi == 2:
         h0 = torch.randn(M, N, generator=g)
         out = h0.clone().to(device)
         L.check(L.lib().mmr_debug_gemm(epi, Ad.data_ptr(), Wd.data_ptr(), M, N, K, bd.data_ptr(), out.data_ptr(), st))
         got, ref = out.cpu(), ref + h0
-        tol = 2e-4 * max(1.0, ref.abs().max().item())
+        bound = torch.full_like(ref, 3e-5 * scale)
     else:
         out = torch.empty(M, N, dtype=torch.float32, device=device)
         L.check(L.lib().mmr_debug_gemm(epi, Ad.data_ptr(), Wd.data_ptr(), M, N, K, bd.data_ptr() if epi == 4 else 0,
                                        out.data_ptr(), st))
         got = out.cpu()
-        tol = 2e-4 * max(1.0, ref.abs().max().item())
-    err = (got - ref).abs().max().item()
-    assert err <= tol, f"gemm epi={epi} {M}x{N}x{K}: max err {err} > {tol}"
+        bound = torch.full_like(ref, 3e-5 * scale)
+    excess = ((got - ref).abs() / bound).max().item()
+    assert excess <= 1.0, f"gemm epi={epi} {M}x{N}x{K}: error is {excess:.2f}x the per-element bound"
 
 
 def test_gemm_rejects_bad_shapes(L, device):
@@ -121,7 +140,37 @@ def test_attention_core(L, device, T, causal):
     qkv_d = qkv.to(device)
     L.check(L.lib().mmr_debug_attention(qkv_d.data_ptr(), o.data_ptr(), B, T, heads, causal, L.stream_ptr(device)))
     err = (o.float().cpu() - ref).abs().max().item()
-    assert err <= 2e-2 * ref.abs().max().item() + 1e-3, f"T={T} causal={causal}: {err}"
+    # measured ~1e-3 of the largest output (bf16 P and bf16 output rounding); the guard is 4e-3, not the old 2e-2
+    assert err <= 4e-3 * ref.abs().max().item() + 1e-4, f"T={T} causal={causal}: {err / ref.abs().max().item():.2e} of max"
+
+
+@pytest.mark.parametrize("T", [1, 19, 50, 64, 77, 96, 97, 130, 257, 300, 512])
+def test_attention_core_with_key_padding_mask(L, device, T):
+    """The non-causal kernels with HF's key-padding `attention_mask` (BERT text tower with padded batches)."""
+    B, heads = 4, 2
+    d = heads * 64
+    g = torch.Generator().manual_seed(1000 + T)
+    qkv = (torch.randn(B * T, 3 * d, generator=g) * 1.5).bfloat16()
+    lens = torch.randint(1, T + 1, (B,), generator=g)
+    lens[0] = T
+    mask = (torch.arange(T)[None, :] < lens[:, None]).int()
+    mask[B - 1] = (torch.rand(T, generator=g) < 0.6).int()          # holes, not only a suffix
+    mask[B - 1, 0] = 1
+    q, k, v = qkv.float().view(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-1, -2)) * 0.125
+    att = att.masked_fill(mask.view(B, 1, 1, T) == 0, float("-inf"))
+    ref = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(B * T, d)
+    o = torch.zeros(B * T, d, dtype=torch.bfloat16, device=device)
+    qkv_d, mask_d = qkv.to(device), mask.to(device)
+    L.check(L.lib().mmr_debug_attention_masked(qkv_d.data_ptr(), o.data_ptr(), B, T, heads, mask_d.data_ptr(), L.stream_ptr(device)))
+    err = (o.float().cpu() - ref).abs().max().item()
+    assert err <= 4e-3 * ref.abs().max().item() + 1e-4, f"T={T}: {err}"
+    # an all-ones mask is bit-identical to the unmasked kernel
+    ones = torch.ones(B, T, dtype=torch.int32, device=device)
+    o1, o2 = torch.zeros_like(o), torch.zeros_like(o)
+    L.check(L.lib().mmr_debug_attention_masked(qkv_d.data_ptr(), o1.data_ptr(), B, T, heads, ones.data_ptr(), L.stream_ptr(device)))
+    L.check(L.lib().mmr_debug_attention(qkv_d.data_ptr(), o2.data_ptr(), B, T, heads, 0, L.stream_ptr(device)))
+    assert torch.equal(o1, o2)
 
 
 # ------------------------------------------------------------------ tower-level
@@ -157,8 +206,8 @@ def test_tiny_vision_stages_vs_golden_and_oracle(L, device, golden_dir, fold):
         # and against the HF golden (fp32 pixels): same bound plus the pixel-rounding effect
         assert np.abs(got.numpy() - g[gold]).max() <= 3e-2 * scale, f"golden {gold}"
     feat = feat.cpu()
-    assert _cos(feat, feat_or).min().item() >= 1 - 1e-3
-    assert _cos(feat, torch.from_numpy(g["image_features"])).min().item() >= 1 - 1e-3
+    _check_cos(feat, feat_or, "tiny vision vs oracle", fold)
+    _check_cos(feat, torch.from_numpy(g["image_features"]), "tiny vision vs HF golden", fold)
 
 
 @FOLD
@@ -178,8 +227,8 @@ def test_tiny_text_vs_golden_and_oracle(L, device, golden_dir, fold):
     ref = st["layer0"]
     assert (tap.cpu().view(N, T, d) - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
     assert np.abs(tap.cpu().view(N, T, d).numpy() - g["t_layer0"]).max() <= 2e-2 * ref.abs().max().item()
-    assert _cos(feat, feat_or).min().item() >= 1 - 1e-3
-    assert _cos(feat, torch.from_numpy(g["text_features"])).min().item() >= 1 - 1e-3
+    _check_cos(feat, feat_or, "tiny text vs oracle", fold)
+    _check_cos(feat, torch.from_numpy(g["text_features"]), "tiny text vs HF golden", fold)
 
 
 @pytest.mark.parametrize("name,fn", [("ViT-B/32", "encoder_ViT-B-32.npz"), ("ViT-B/16", "encoder_ViT-B-16.npz"),
@@ -188,7 +237,7 @@ def test_tiny_text_vs_golden_and_oracle(L, device, golden_dir, fold):
 @FOLD
 def test_full_models_vs_hf_golden(device, golden_dir, name, fn, fold):
     g = np.load(os.path.join(golden_dir, fn))
-    model, _ = mmr_amd.load(name, device=device, seed=int(g["weight_seed"]), fold_ln=fold)
+    model, _ = mmr_amd.load(name, device=device, weights="synthetic", seed=int(g["weight_seed"]), fold_ln=fold)
     assert model.dtype == torch.float32
     ccfg = model.cfg
     px = synth.synth_images(int(g["n_img"]), ccfg.vision.image_size, seed=int(g["image_seed"]))
@@ -196,13 +245,13 @@ def test_full_models_vs_hf_golden(device, golden_dir, name, fn, fold):
     gold = torch.from_numpy(g["image_features"])
     cos = _cos(img, gold)
     rel = ((img - gold).norm(dim=-1) / gold.norm(dim=-1)).max().item()
-    print(f"{name}: image cos min {cos.min().item():.6f}, rel L2 err {rel:.4f}")
-    assert cos.min().item() >= 1 - 1e-3
+    print(f"{name}: image 1-cos max {1 - cos.min().item():.2e}, rel L2 err {rel:.4f}")
+    _check_cos(img, gold, f"{name} image vs HF golden", fold)
     if "text_features" in g:
         ids = synth.synth_token_ids(int(g["n_txt"]), ccfg.text.tokens, ccfg.text.vocab, seed=int(g["text_seed"]))
         txt = model.encode_text(ids.to(device)).cpu()
         tg = torch.from_numpy(g["text_features"])
-        assert _cos(txt, tg).min().item() >= 1 - 1e-3
+        _check_cos(txt, tg, f"{name} text vs HF golden", fold)
         lpi, lpt = model(px.to(device), ids.to(device))
         scale = float(model.logit_scale.exp())
         # logits = scale * cosine: 1e-3 cosine tolerance
@@ -264,7 +313,7 @@ def test_batch_256_vitb32_matches_oracle_on_sample(device, fold):
     """BASELINE cfg2 shape (B=256, ViT-B/32 bf16): every row finite, rows independent of batch position,
     and a sample of rows checked against the fp32 oracle."""
     from oracle import clip_ref
-    model, _ = mmr_amd.load("ViT-B/32", device=device, fold_ln=fold)
+    model, _ = mmr_amd.load("ViT-B/32", device=device, weights="synthetic", fold_ln=fold)
     model.bfloat16()
     px = synth.synth_images(256, 224, seed=2)
     f = model.encode_image(px.to(device), normalize=True)
@@ -280,8 +329,8 @@ def test_batch_256_vitb32_matches_oracle_on_sample(device, fold):
     w = weights.make_clip_weights(model.cfg)
     with torch.no_grad():
         ref = clip_ref.l2_normalize(clip_ref.encode_image(w, model.cfg.vision, px[[0, 255]].bfloat16().float()))
-    cos = _cos(f[[0, 255]].float().cpu(), ref)
-    assert cos.min().item() >= 1 - 1e-3
+    # bf16 OUTPUT features here (model.bfloat16()): 512 components rounded to 8 bits add ~4e-6 to 1 - cos
+    _check_cos(f[[0, 255]].float().cpu(), ref, "ViT-B/32 batch 256 vs oracle", fold)
 
 
 def test_encode_gallery_and_cache(device, tmp_path):
@@ -325,7 +374,7 @@ def test_baseline_config0_and_config2_end_to_end(device):
     gallery, seeds 0 / 1) and configs[2] shape (text tower -> search): the ranking computed on the device features
     is bit-exact against the oracle ranking of those same features, and the features match the fp32 oracle."""
     from oracle import clip_ref, search_ref
-    model, _ = mmr_amd.load("ViT-B/32", device=device)
+    model, _ = mmr_amd.load("ViT-B/32", device=device, weights="synthetic")
     px = synth.synth_images(128, 224, seed=0)
     feats = model.encode_image(px.to(device))                       # fp32 outputs, like the reference on CPU
     feats /= feats.norm(dim=-1, keepdim=True)                       # the reference's in-place normalise
@@ -337,7 +386,7 @@ def test_baseline_config0_and_config2_end_to_end(device):
     w = weights.make_clip_weights(model.cfg)
     with torch.no_grad():
         ref = clip_ref.l2_normalize(clip_ref.encode_image(w, model.cfg.vision, px[:3].bfloat16().float()))
-    assert _cos(feats[:3].cpu(), ref).min().item() >= 1 - 1e-3
+    _check_cos(feats[:3].cpu(), ref, "cfg1 features vs oracle")
     # cosine scores of the device features vs the oracle features against the same gallery: within 1e-3
     assert (feats[:3].cpu() @ gal.t() - ref @ gal.t()).abs().max().item() <= 1e-3
     # configs[2]: text -> image search over a bf16 gallery built from encoded images
@@ -391,7 +440,7 @@ def test_bf16_pixels_fused_patch_gather_equals_im2col_path(device):
     """bf16 pixels at patch 32 take the GEMM with the patch gather fused into its A-tile loads (no im2col pass); fp32
     pixels holding the same values go through im2col + the plain GEMM.  Same operands, same kernel arithmetic:
     the features must agree bit for bit, at the bench's batch (fused) and at a small one (falls back to im2col)."""
-    model, _ = mmr_amd.load("ViT-B/32", device=device)
+    model, _ = mmr_amd.load("ViT-B/32", device=device, weights="synthetic")
     px = synth.synth_images(256, 224, seed=21).bfloat16()
     f_fused = model.encode_image(px.to(device))
     f_plain = model.encode_image(px.float().to(device))
@@ -401,3 +450,107 @@ def test_bf16_pixels_fused_patch_gather_equals_im2col_path(device):
     # ragged batch: 300 images are processed as one 300-image launch sequence (padding rows re-read the last patch)
     px2 = synth.synth_images(300, 224, seed=22).bfloat16()
     assert torch.equal(model.encode_image(px2.to(device)), model.encode_image(px2.float().to(device)))
+
+
+def test_no_host_sync_surface_details(device):
+    """Round-2 surface items: token ids that already live on the GPU are not read back (the embedding kernel clamps and
+    raises the status word); `preprocess` follows the model's dtype; the HF `CLIPProcessor` spelling
+    (reference code/test_taiyi.py:18-23) runs; exp(logit_scale) is a cached host number."""
+    import mmr_amd as clip
+    model, preprocess = clip.load("tiny-test", device=device)
+    S, V = model.input_resolution, model.cfg.text.vocab
+    ids = synth.synth_token_ids(3, 77, V)
+    ok = model.encode_text(ids.to(device))
+    assert not model.text_id_errors()
+    bad = ids.clone()
+    bad[1, 5] = V + 7
+    with pytest.raises(IndexError):
+        model.encode_text(bad)                                    # host ids: checked on the host, as before
+    out = model.encode_text(bad.to(device))                       # device ids: clamped, flagged, no exception
+    assert model.text_id_errors() and torch.isfinite(out).all()
+    assert torch.equal(out[0], ok[0]) and torch.equal(out[2], ok[2])
+    assert torch.equal(model.encode_text(ids.to(device)), ok) and not model.text_id_errors()
+    assert abs(model._logit_scale_exp - float(model.logit_scale.exp())) < 1e-4
+    # preprocess dtype follows the model (fp32 like the reference's preprocess; bf16 after .bfloat16()), and an explicit
+    # request wins; bf16 pixels give bit-identical features (the encoder rounds pixels to bf16 on the way in)
+    raw = torch.randint(0, 255, (50, 70, 3), dtype=torch.uint8)
+    p32 = preprocess(raw)
+    assert p32.dtype == torch.float32 and p32.shape == (3, S, S) and p32.is_cuda
+    f32 = model.encode_image(p32.unsqueeze(0))
+    model.bfloat16()
+    p16 = preprocess(raw)
+    assert p16.dtype == torch.bfloat16 and torch.equal(p16, p32.bfloat16())
+    assert preprocess(raw, dtype=torch.float32).dtype == torch.float32
+    model.float()
+    assert torch.equal(model.encode_image(p16.unsqueeze(0)), f32)
+    _, pre16 = clip.load("tiny-test", device=device, pixel_dtype=torch.bfloat16)
+    assert pre16(raw).dtype == torch.bfloat16
+    # HF spelling: image = processor(images=..., return_tensors="pt"); model.get_image_features(**image)
+    image = model.processor(images=raw.numpy(), return_tensors="pt")
+    assert image["pixel_values"].shape == (1, 3, S, S) and torch.equal(image.pixel_values[0], p32)
+    assert torch.equal(model.get_image_features(**image), f32)
+    two = model.processor(images=[raw.numpy(), raw.numpy()], return_tensors="pt").to(device)
+    assert two.pixel_values.shape == (2, 3, S, S)
+    with pytest.raises(ValueError):
+        model.processor()
+
+
+@pytest.mark.parametrize("name,batch", [("tiny-test", 3), ("ViT-B/32", 1), ("ViT-B/32", 10)])
+def test_encode_is_graph_capturable_and_replay_is_bit_identical(device, name, batch):
+    """include/mmr.h promises the forward is hipGraph-capturable (no allocation, no sync, no host read of device
+    data).  Capture encode_image + encode_text + a GalleryIndex search in one graph on a side stream, replay it on new
+    inputs, and require bit-identical results to the eager calls (the reference's own loops run batch 1 and 10:
+    reference code/search_image.py:153-158, 305-316)."""
+    import mmr_amd as clip
+    from mmr_amd import search
+    model, _ = clip.load(name, device=device, weights="synthetic")
+    S, V, T = model.input_resolution, model.cfg.text.vocab, model.cfg.text.tokens
+    g = torch.Generator().manual_seed(3)
+    px = [torch.randn(batch, 3, S, S, generator=g).to(device) for _ in range(2)]
+    ids = [synth.synth_token_ids(2, T, V, seed=s).to(device) for s in (1, 2)]
+    gal = synth.synth_unit_rows(4000, model.cfg.embed_dim, seed=9).to(device)
+    index = search.GalleryIndex(gal)
+    eager = []
+    for p, t in zip(px, ids):
+        f = model.encode_image(p, normalize=True)
+        eager.append((f.clone(), model.encode_text(t).clone(), [x.clone() for x in index.search(f, 5)]))
+    static_px, static_ids = px[0].clone(), ids[0].clone()
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        model.encode_image(static_px, normalize=True); model.encode_text(static_ids); index.search(eager[0][0], 5)   # warm
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            gf = model.encode_image(static_px, normalize=True)
+            gt = model.encode_text(static_ids)
+            gs, gi = index.search(gf, 5)
+    torch.cuda.current_stream(device).wait_stream(side)
+    for k in (0, 1, 0):
+        static_px.copy_(px[k]); static_ids.copy_(ids[k])
+        graph.replay()
+        torch.cuda.synchronize(device)
+        assert torch.equal(gf, eager[k][0]) and torch.equal(gt, eager[k][1])
+        assert torch.equal(gs, eager[k][2][0]) and torch.equal(gi, eager[k][2][1])
+
+
+@pytest.mark.slow
+def test_vit_l14_336_batch_128_configs4_shape(device):
+    """BASELINE configs[4] per-GPU shape: ViT-L/14@336 bf16, batch 128 (73 856 token rows, streaming attention at
+    T = 577): every row finite, rows independent of their batch position, two rows checked against the fp32 oracle,
+    and the features searchable against a 768-d gallery."""
+    from oracle import clip_ref
+    model, _ = mmr_amd.load("ViT-L/14@336px", device=device, weights="synthetic")
+    model.bfloat16()
+    px = synth.synth_images(128, 336, seed=2)
+    f = model.encode_image(px.to(device).bfloat16(), normalize=True)
+    assert f.dtype == torch.bfloat16 and f.shape == (128, 768) and torch.isfinite(f.float()).all()
+    f1 = model.encode_image(px[60:62].to(device).bfloat16(), normalize=True)
+    assert torch.equal(f[60:62], f1)                     # same features whatever batch a row is encoded in
+    w = weights.make_clip_weights(model.cfg)
+    with torch.no_grad():
+        ref = clip_ref.l2_normalize(clip_ref.encode_image(w, model.cfg.vision, px[[0, 127]].bfloat16().float()))
+    c = _check_cos(f[[0, 127]].float().cpu(), ref, "ViT-L/14@336 batch 128 vs oracle")
+    print(f"ViT-L/14@336 B=128: 1 - cos = {c:.2e}")
+    gal = synth.synth_unit_rows(20_000, 768, seed=9).bfloat16().to(device)
+    vals, idx = mmr_amd.cosine_topk(f, gal, 10)
+    assert idx.shape == (128, 10) and (idx >= 0).all()

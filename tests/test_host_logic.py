@@ -119,6 +119,19 @@ def test_tokenize_strings_with_a_merge_table(tmp_path):
     assert out.shape == (2, 77) and out[0, 0] == out[1, 0] and (out[0] != 0).sum() == 3   # SOT cat EOT
 
 
+def test_load_without_checkpoint_raises_instead_of_encoding_noise(tmp_path):
+    """clip.load("ViT-B/32") with no checkpoint reachable must not hand back a random-weight model silently."""
+    with pytest.raises(FileNotFoundError) as e:
+        mmr_amd.load("ViT-B/32", device="cuda")
+    assert "synthetic" in str(e.value)
+    with pytest.raises(FileNotFoundError):
+        mmr_amd.load("ViT-L/14", device="cuda", download_root=str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        mmr_amd.load_text_encoder("IDEA-CCNL/Taiyi-CLIP-Roberta-large-326M-Chinese", device="cuda")
+    with pytest.raises(RuntimeError):
+        mmr_amd.load("RN50", device="cuda")            # unknown architecture: same error as before
+
+
 def test_no_gpu_means_loud_failure():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
@@ -162,6 +175,15 @@ def _sharded_worker(rank, world, port, q):
         score2, idx2 = index.search(queries, 40, 1.0)
         oi2, _, _ = search_ref.cosine_topk(queries, gal, 40, 1.0)
         ok = ok and bool(np.array_equal(idx2.numpy(), oi2))
+        # a single 1-D query (the reference's ref_feature form): 1-D results on the sharded path too
+        s1, i1 = index.search(queries[0], 10, 100.0)
+        ok = ok and i1.shape == (10,) and s1.shape == (10,) and bool(np.array_equal(i1.numpy(), oi[0]))
+        # pipelined batches: batch i's all-gather is in flight while batch i+1 is searched locally
+        outs = index.search_pipelined([queries[:2], queries[2:5], queries[5:]], 10, 100.0)
+        ok = ok and bool(np.array_equal(torch.cat([o[1] for o in outs]).numpy(), oi))
+        ok = ok and bool(np.array_equal(torch.cat([o[0] for o in outs]).numpy(), os_))
+        pend = index.search_async(queries, 10, 100.0)          # explicit handle form
+        ok = ok and bool(np.array_equal(pend.result()[1].numpy(), oi))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

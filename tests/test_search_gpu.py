@@ -111,6 +111,65 @@ def test_uncertified_queries_fall_back_to_exact(S, oracle, device):
     assert int(status[1]) == 0          # ordinary query -> fast path
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_unnormalised_gallery_certificate_is_sized_from_the_data(S, oracle, device, dtype):
+    """Raw encode_image rows are NOT unit-norm (|f| ~ 25 for the seeded ViT-B/32).  The certificate's margin must come
+    from the gallery's real row norms, not from a caller's promise: with rows scaled 5-30x and a crowded top-k
+    boundary (the near-tie construction of test_uncertified_queries_fall_back_to_exact) the result stays bit-exact
+    and the crowded query is sent down the exhaustive path -- through cosine_topk without a bound (measured per call),
+    through GalleryIndex (measured once) and even when the caller UNDERSTATES the bound to the index."""
+    E, N = 512, 8192
+    g = torch.Generator().manual_seed(5)
+    scales = 5.0 + 25.0 * torch.rand(N, 1, generator=g)
+    scales[5] = 20.0                                    # the duplicated row scores ~20: above any unrelated row (<= ~6)
+    gal = (synth.synth_unit_rows(N, E, seed=21) * scales).to(dtype)
+    base = gal[5].clone()
+    rows = torch.randperm(N, generator=g)[:60]
+    for j, r in enumerate(rows.tolist()):
+        v = base.clone()
+        if dtype == torch.bfloat16:
+            v.view(torch.int16)[j] += (j % 5) - 2          # a few ulps on one component
+        else:
+            v.view(torch.int32)[j] += ((j % 5) - 2) * 3
+        gal[r] = v
+    q = torch.stack([base.float() / base.float().norm(), synth.synth_unit_rows(1, E, seed=22)[0]]).to(dtype)
+    oi, os_, od = oracle.cosine_topk(q, gal, 10)
+    gd, qd = gal.to(device), q.to(device)
+    nb = S.gallery_norm_bound(gd)
+    true_max = gal.double().norm(dim=-1).max().item()
+    assert true_max <= float(nb) <= true_max * 1.001
+    for how in ("per-call", "index", "index-understated"):
+        if how == "per-call":
+            vals, idx, d64, status = S.cosine_topk(qd, gd, 10, return_dot64=True, return_status=True)
+        else:
+            index = S.GalleryIndex(gd, norm_bound=1.0 if how == "index-understated" else None)
+            vals, idx, d64, status = index.search(qd, 10, return_dot64=True, return_status=True)
+        assert np.array_equal(idx.cpu().numpy(), oi), how
+        assert np.array_equal(d64.cpu().numpy(), od), how
+        assert int(status[0]) == 1 and int(status[1]) == 0, (how, status.tolist())
+    # an honest explicit bound is used as given (no measuring pass) and gives the same answer
+    vals, idx, status = S.cosine_topk(qd, gd, 10, gallery_norm_bound=31.0, return_status=True)
+    assert np.array_equal(idx.cpu().numpy(), oi) and int(status[0]) == 1
+    with pytest.raises(ValueError):
+        S.cosine_topk(qd, gd, 10, gallery_norm_bound=float("inf"))
+
+
+def test_index_one_dimensional_query_shapes(S, oracle, device):
+    """A single 1-D query (the reference's ref_feature form): every output is squeezed the same way."""
+    gal = synth.synth_unit_rows(3000, 512, seed=61).bfloat16()
+    q = synth.synth_unit_rows(1, 512, seed=62).bfloat16()[0]
+    oi, os_, od = oracle.cosine_topk(q.unsqueeze(0), gal, 10)
+    index = S.GalleryIndex(gal.to(device))
+    score, idx, d64 = index.search(q.to(device), 10, return_dot64=True)
+    assert score.shape == idx.shape == d64.shape == (10,)
+    assert np.array_equal(idx.cpu().numpy(), oi[0]) and np.array_equal(d64.cpu().numpy(), od[0])
+    sh = S.ShardedGalleryIndex(gal.to(device))            # no process group: one local shard, same code path
+    s2, i2 = sh.search(q.to(device), 10)
+    assert i2.shape == (10,) and np.array_equal(i2.cpu().numpy(), oi[0])
+    outs = sh.search_pipelined([q.to(device).unsqueeze(0)] * 3, 10)
+    assert all(np.array_equal(o[1].cpu().numpy(), oi) for o in outs)
+
+
 def test_fp32_gallery_fast_path_and_fallback(S, oracle, device):
     """fp32 galleries (the dtype of the reference's feature caches) take the fp32-MFMA scan; crowded boundaries
     still fall back to the exhaustive path and stay exact."""
@@ -181,14 +240,18 @@ def test_error_paths(S, device):
 
 
 @pytest.mark.slow
-def test_full_size_1m_gallery_exact(S, oracle, device):
-    """BASELINE cfg2 size: 1M x 512 bf16, Q=256, k=10 -- indices bit-exact vs the oracle on a query
-    sample, plus size-independent properties on all queries."""
-    N, E, Q, k = 1_000_000, 512, 256, 10
+@pytest.mark.parametrize("N,E,Q", [(1_000_000, 512, 256),      # BASELINE configs[1]/[2]: the 1M x 512 gallery
+                                   (1_250_000, 512, 256),      # configs[3]: one GPU's shard of the 10M gallery
+                                   (1_000_000, 768, 128)])     # configs[4]: the E = 768 (ViT-L/14) shard
+def test_full_size_gallery_exact(S, oracle, device, N, E, Q):
+    """BASELINE-size shards, k=10 -- indices bit-exact vs the oracle on a query sample, plus size-independent
+    properties on all queries."""
+    k = 10
     gal = synth.synth_unit_rows(N, E, seed=3, dtype=torch.bfloat16)
     q = synth.synth_unit_rows(Q, E, seed=4, dtype=torch.bfloat16)
     gd = gal.to(device)
-    vals, idx, d64, status = S.cosine_topk(q.to(device), gd, k, return_dot64=True, return_status=True)
+    index = S.GalleryIndex(gd)
+    vals, idx, d64, status = index.search(q.to(device), k, return_dot64=True, return_status=True)
     idx_c, d_c = idx.cpu(), d64.cpu()
     # properties: sorted by (-dot,+idx), ids unique and in range, dots re-computable from the rows
     assert (d_c[:, :-1] >= d_c[:, 1:]).all()
@@ -201,12 +264,24 @@ def test_full_size_1m_gallery_exact(S, oracle, device):
     sub = gd[idx[0]]
     _, i2 = S.cosine_topk(q[:1].to(device), sub, k)
     assert i2[0].tolist() == list(range(k))
-    # oracle on a sample of queries (exhaustive fp64 over 1M rows on the CPU)
-    sample = [0, 17, 255]
+    # the (k+1)-th best bounds everything that was left out: top-(k+1) extends top-k
+    _, i11 = index.search(q[:8].to(device), k + 1)
+    assert torch.equal(i11[:, :k].cpu(), idx_c[:8])
+    # oracle on a sample of queries (exhaustive fp64 over all rows on the CPU)
+    sample = [0, 17, Q - 1]
     oi, _, od = oracle.cosine_topk(q[sample], gal, k)
     assert np.array_equal(idx_c[sample].numpy(), oi)
     assert np.array_equal(d_c[sample].numpy(), od)
     print("status (queries on exhaustive path):", int(status.sum()))
+    assert int(status.sum()) <= 2, "the certificate should pass (almost) every query of a random unit gallery"
+    # a 4-way split of the same shard + merge == the unsplit result (the sharded path's arithmetic at this size)
+    cuts = [0, N // 4, N // 2, 3 * N // 4, N]
+    pi, pd = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        _, i, d = S.cosine_topk(q.to(device), gd[a:b], k, return_dot64=True)
+        pi.append(torch.where(i >= 0, i + a, i)); pd.append(d)
+    _, mi, md = S.merge_topk(torch.stack(pi), torch.stack(pd), 1.0)
+    assert torch.equal(mi.cpu(), idx_c) and torch.equal(md.cpu(), d_c)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
@@ -280,5 +355,9 @@ def test_sharded_index_over_rccl(S, oracle, device):
         oi, os_, _ = oracle.cosine_topk(q, gal, 10, 100.0)
         assert idx.dtype == torch.int64
         assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(score.cpu().numpy(), os_)
+        s1, i1 = index.search(q[3].to(device), 10, 100.0)          # 1-D query through the collective
+        assert i1.shape == (10,) and np.array_equal(i1.cpu().numpy(), oi[3])
+        outs = index.search_pipelined([q[:5].to(device), q[5:].to(device)], 10, 100.0)   # async all-gathers in flight
+        assert np.array_equal(torch.cat([o[1] for o in outs]).cpu().numpy(), oi)
     finally:
         dist.destroy_process_group()

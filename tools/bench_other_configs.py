@@ -37,7 +37,7 @@ res = {"note": "1 x MI355X, synthetic device-resident inputs, seeded random-init
 
 # configs[2]: text-to-image -- CLIP text tower bf16 (ViT-B/32's) on 256 prompts, their features as the queries of a
 # top-10 search over a 1M x 512 image gallery
-model, _ = mmr_amd.load("ViT-B/32", device=dev)
+model, _ = mmr_amd.load("ViT-B/32", device=dev, weights="synthetic")
 model.bfloat16()
 ids = synth.synth_token_ids(256, 77, model.vocab_size, seed=5).to(dev)
 gal = unit_rows(1_000_000, 512, 3)
@@ -71,7 +71,7 @@ model = None
 torch.cuda.empty_cache()
 
 # configs[4]: ViT-L/14@336 bf16, batch 128 per GPU, + search over a 768-d gallery
-model, _ = mmr_amd.load("ViT-L/14@336px", device=dev)
+model, _ = mmr_amd.load("ViT-L/14@336px", device=dev, weights="synthetic")
 model.bfloat16()
 px = torch.randn(128, 3, 336, 336, device=dev).bfloat16()
 gal = unit_rows(1_000_000, 768, 9)

@@ -7,7 +7,7 @@ import mmr_amd
 from mmr_amd import search, synth
 
 dev = torch.device("cuda:0")
-model, _ = mmr_amd.load(os.environ.get("MODEL", "ViT-B/32"), device=dev)
+model, _ = mmr_amd.load(os.environ.get("MODEL", "ViT-B/32"), device=dev, weights="synthetic")
 model.bfloat16()
 B = int(os.environ.get("B", 256))
 S = model.input_resolution

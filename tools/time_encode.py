@@ -7,7 +7,7 @@ import mmr_amd
 dev = torch.device("cuda:0")
 name = os.environ.get("MODEL", "ViT-B/32")
 B = int(os.environ.get("B", 256))
-model, _ = mmr_amd.load(name, device=dev)
+model, _ = mmr_amd.load(name, device=dev, weights="synthetic")
 model.bfloat16()
 S = model.input_resolution
 px = torch.randn(B, 3, S, S, device=dev).bfloat16()

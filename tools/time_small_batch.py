@@ -5,7 +5,7 @@ import torch
 import mmr_amd
 
 dev = torch.device("cuda:0")
-model, _ = mmr_amd.load("ViT-B/32", device=dev)
+model, _ = mmr_amd.load("ViT-B/32", device=dev, weights="synthetic")
 for B in [int(x) for x in os.environ.get("BS", "1,8,32,64").split(",")]:
     px = torch.randn(B, 3, 224, 224, device=dev)
     for _ in range(3):

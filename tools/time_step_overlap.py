@@ -7,7 +7,7 @@ import mmr_amd
 from mmr_amd import search, synth
 
 dev = torch.device("cuda:0")
-model, _ = mmr_amd.load("ViT-B/32", device=dev)
+model, _ = mmr_amd.load("ViT-B/32", device=dev, weights="synthetic")
 model.bfloat16()
 px = torch.randn(256, 3, 224, 224, device=dev).bfloat16()
 gal = torch.randn(1_000_000, 512, device=dev)
