@@ -219,6 +219,150 @@ __global__ __launch_bounds__(ScanCfg<E>::SCAN_THREADS, ScanCfg<E>::SCAN_WAVES / 
 }
 
 // ---------------------------------------------------------------------------------------------
+// scan for wide rows (E = 768, the ViT-L/14 embedding; BASELINE configs[4]).  32 resident queries of 768 dims are 192
+// VGPRs, which forced the 32x32 form above down to one wave per SIMD with the queries parked in AccVGPRs and copied
+// back in front of every MFMA (0.33 of the HBM roof).  Here each of 8 waves keeps 16 queries (96 VGPRs) and multiplies
+// with v_mfma_f32_16x16x32_bf16: the same 128 queries per pass, but two waves per SIMD (one reads LDS while the other
+// issues MFMAs), no register shuffling, and the 16x16 shape's higher sustained clock.  A 32-row tile is two 16-row
+// blocks with one accumulator chain each.  Same LDS image, staging ring, counted waits and bmax/tmax outputs as
+// scan_kernel, so the finalize kernels do not care which scan ran.
+//   B operand: lane (c = lane & 15, g = lane >> 4) holds elements [32s + 8g, +8) of query wave*16 + c for k-step s;
+//   A operand: the same 8 elements of tile row 16*rb + c;  D: acc[i] = dot(query c, tile row 16*rb + 4g + i).
+// Bank check for the A reads (ds_read_b128, 16-lane groups {0-3,12-15,20-27} ...): a group's lanes read rows
+// {0-3,12-15} at chunk 4s and rows {4-11} at chunk 4s+1; slot = (chunk ^ row) & 15 gives 16 distinct slots.
+// ---------------------------------------------------------------------------------------------
+template <int E>
+struct Scan16Cfg {
+    static constexpr int SCAN_WAVES = 8;
+    static constexpr int SCAN_THREADS = SCAN_WAVES * 64;
+    static constexpr int QMAX = SCAN_WAVES * 16;      // 128 queries per scan pass
+    static constexpr int CH = E / 8;
+    static constexpr int ROWB = E * 2;
+    static constexpr int TILE_BYTES = TILE_ROWS * ROWB;
+    static constexpr int LOADS = TILE_ROWS * CH / 64;
+    static constexpr int LPW = LOADS / SCAN_WAVES;
+    static constexpr int KSTEPS = E / 32;
+    static_assert(LOADS % SCAN_WAVES == 0 && CH % 16 == 0, "tile geometry");
+};
+
+template <int E>
+__global__ __launch_bounds__(Scan16Cfg<E>::SCAN_THREADS, 2) void scan16_kernel(
+    const bf16_t *__restrict__ q, const bf16_t *__restrict__ gal, int Q, int64_t N, int ntiles, int tpt,
+    int qwaves, int qpad, float *__restrict__ bmax, float *__restrict__ tmax)
+{
+    using C = Scan16Cfg<E>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int task = blockIdx.x;
+    const int t0 = task * tpt;
+    const int t1 = min(ntiles, t0 + tpt);
+    const bool compute = wave < qwaves;
+
+    bf16x8 bq[C::KSTEPS];
+    {
+        const int qrow = wave * 16 + c;
+        const bool live = compute && qrow < Q;
+        const bf16_t *qp = q + (size_t)(live ? qrow : 0) * E + g * 8;
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            bf16x8 v = *reinterpret_cast<const bf16x8 *>(qp + s * 32);
+            bq[s] = live ? v : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    auto stage = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < C::LPW; ++i) {
+            const int instr = wave * C::LPW + i;
+            const int p = instr * 64 + lane;
+            const int row = p / C::CH;
+            const int pos = p % C::CH;
+            const int chunk = (pos & ~15) | ((pos ^ row) & 15);
+            int64_t grow = (int64_t)tile * TILE_ROWS + row;
+            grow = grow < N ? grow : N - 1;
+            glds16(gal + grow * E + chunk * 8, smem + buf * C::TILE_BYTES + instr * 1024);
+        }
+    };
+    float task_max = -INFINITY, pend = -INFINITY;
+    int pend_tile = -1;
+    constexpr int PD = SCAN_NBUF - 1;
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+        if (t0 + i < t1) stage(t0 + i, i);
+    int cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        const int younger = min(PD - 1, t1 - 1 - t);
+        if (younger >= 2) wait_vmcnt<2 * C::LPW>();
+        else if (younger == 1) wait_vmcnt<C::LPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (compute && pend_tile >= 0 && g == 0) bmax[(size_t)pend_tile * qpad + wave * 16 + c] = pend;
+        int nxt = cur + PD; nxt = nxt >= SCAN_NBUF ? nxt - SCAN_NBUF : nxt;
+        if (t + PD < t1) stage(t + PD, nxt);
+        if (compute) {
+            const char *tb = smem + cur * C::TILE_BYTES;
+            // step u = 2*s + rb: k-step s of row block rb; the two row blocks alternate, so consecutive MFMAs belong to
+            // different accumulation chains.  Fragment reads run PF steps ahead (inline asm + counted lgkmcnt: see scan_kernel).
+            constexpr int NU = 2 * C::KSTEPS;
+            constexpr int PF = 6;
+            f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+            bf16x8 a[PF];
+            auto issue = [&](int u, bf16x8 &dst) {
+                const int s = u >> 1, rb = u & 1;
+                const int row = rb * 16 + c;
+                const int chunk = 4 * s + g;
+                const int pos = (chunk & ~15) | ((chunk ^ row) & 15);
+                const uint32_t addr = (uint32_t)(uintptr_t)(tb + row * C::ROWB + pos * 16);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
+            };
+#pragma unroll
+            for (int u = 0; u < PF; ++u) issue(u, a[u]);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int younger_r = (NU - 1 - u) < (PF - 1) ? (NU - 1 - u) : (PF - 1);
+                if (younger_r == 5) asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(a[u % PF]));
+                else if (younger_r == 4) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a[u % PF]));
+                else if (younger_r == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(a[u % PF]));
+                else if (younger_r == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a[u % PF]));
+                else if (younger_r == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(a[u % PF]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a[u % PF]));
+                if (u & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u % PF], bq[u >> 1], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u % PF], bq[u >> 1], acc0, 0, 0, 0);
+                if (u + PF < NU) {
+                    // the MFMA above must have read a[u % PF] before the next load overwrites it
+                    if (u & 1) asm volatile("" : "+v"(acc1)); else asm volatile("" : "+v"(acc0));
+                    issue(u + PF, a[u % PF]);
+                }
+            }
+            // acc0[i] = dot(query c, tile row 4g + i); acc1[i]: tile row 16 + 4g + i
+            float m = -INFINITY;
+            if ((int64_t)(t + 1) * TILE_ROWS <= N) {
+                m = fmaxf(fmaxf(fmaxf(acc0[0], acc0[1]), fmaxf(acc0[2], acc0[3])),
+                          fmaxf(fmaxf(acc1[0], acc1[1]), fmaxf(acc1[2], acc1[3])));
+            } else {
+                const int64_t base = (int64_t)t * TILE_ROWS + 4 * g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    m = fmaxf(m, base + i < N ? acc0[i] : -INFINITY);
+                    m = fmaxf(m, base + 16 + i < N ? acc1[i] : -INFINITY);
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            task_max = fmaxf(task_max, m);
+            pend = m;
+            pend_tile = t;
+        }
+        cur = cur + 1 >= SCAN_NBUF ? 0 : cur + 1;
+    }
+    if (compute && g == 0) {
+        if (pend_tile >= 0) bmax[(size_t)pend_tile * qpad + wave * 16 + c] = pend;
+        tmax[(size_t)task * qpad + wave * 16 + c] = task_max;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // scan for fp32 galleries (the dtype of the reference's feature caches): same pipeline, 16-row
 // tiles, v_mfma_f32_16x16x4_f32 (exact fp32 fma chain, 1/16 of the bf16 MFMA rate -> MFMA-bound).
 // Each wave keeps 16 queries resident (E/4 VGPRs); lane (r, g) owns the 16-byte chunk 4S+g of row r
@@ -1110,6 +1254,24 @@ static int launch_scan(const bf16_t *q, const bf16_t *gal, int Qc, int64_t N, co
 }
 
 template <int E>
+static int launch_scan16(const bf16_t *q, const bf16_t *gal, int Qc, int64_t N, const SearchPlan &p, int qpad,
+                         float *bmax, float *tmax, hipStream_t st)
+{
+    ProfScope prof(MMR_PROF_SCAN, st);
+    using C = Scan16Cfg<E>;
+    const int lds = SCAN_NBUF * C::TILE_BYTES;
+    static DeviceOnce once;
+    if (once.first()) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan16_kernel<E>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    hipLaunchKernelGGL(scan16_kernel<E>, dim3(p.ntasks), dim3(C::SCAN_THREADS), lds, st, q, gal, Qc, N, p.ntiles, p.tpt,
+                       qpad / 16, qpad, bmax, tmax);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+template <int E>
 static int launch_scan_f32(const float *q, const float *gal, int Qc, int64_t N, const SearchPlan &p, int qpad,
                            float *bmax, float *tmax, hipStream_t st)
 {
@@ -1263,7 +1425,12 @@ static int cosine_topk_impl(const void *q, const void *gallery, mmr_dtype dtype,
                     case 128: rc = launch_scan<128>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
                     case 256: rc = launch_scan<256>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
                     case 512: rc = launch_scan<512>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                    default: rc = launch_scan<768>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    default: {
+                        // MMR_SCAN768=32 keeps the one-wave-per-SIMD 32x32 form for A/B comparisons
+                        static const int form = getenv("MMR_SCAN768") ? atoi(getenv("MMR_SCAN768")) : 16;
+                        rc = form == 32 ? launch_scan<768>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st)
+                                        : launch_scan16<768>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st);
+                    } break;
                 }
             } else {
                 switch (E) {
