@@ -76,6 +76,7 @@ __device__ __forceinline__ float epi_act(float v) {
 #define MMR_GEMM_NT_STORE 0
 #endif
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 template <typename V>
 __device__ __forceinline__ void epi_store16(void *dst, const V &v) {
     static_assert(sizeof(V) == 16, "16-byte vector");
@@ -85,6 +86,23 @@ __device__ __forceinline__ void epi_store16(void *dst, const V &v) {
     *reinterpret_cast<V *>(dst) = v;
 #endif
 }
+
+// diagnostic build (-DMMR_GEMM_STAMPS): wave 0 of every workgroup records s_memrealtime (100 MHz) at the phase
+// boundaries of each tile it runs into a buffer no kernel reads; mmr_debug_gemm_stamps copies it out
+// (tools/gemm_phase_times.py).  The shipped build has no stamp instruction.
+#ifdef MMR_GEMM_STAMPS
+__device__ unsigned long long mmr_stamp_buf[8192 * 4];
+__device__ unsigned long long mmr_cycle_buf[8192 * 4];      // s_memtime (shader clock) at the same points: clock = d(cycles)/d(realtime)
+#define MMR_STAMP(slot, which)                                                                                  \
+    do {                                                                                                        \
+        if (threadIdx.x == 0 && (slot) < 8192) {                                                                \
+            mmr_stamp_buf[(slot) * 4 + (which)] = __builtin_amdgcn_s_memrealtime();                             \
+            mmr_cycle_buf[(slot) * 4 + (which)] = __builtin_amdgcn_s_memtime();                                 \
+        }                                                                                                       \
+    } while (0)
+#else
+#define MMR_STAMP(slot, which) do { } while (0)
+#endif
 
 // byte offset of 16-B chunk `c` (0..7) of tile row `row` inside a [rows][64] bf16 tile image
 __device__ __forceinline__ int tile_off(int row, int c) {
@@ -309,42 +327,44 @@ constexpr int HALF_BYTES = 128 * BK * 2;            // 16 KiB: 128 rows x 64 bf1
 constexpr int STAGE2_BYTES = 4 * HALF_BYTES;        // A0 A1 W (up to 256 rows, contiguous image)
 constexpr int GEMM2_LDS = 2 * STAGE2_BYTES;         // 128 KiB
 
-template <int EPI, int NIW, bool PATCH = false>
-__global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
-    const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
-    const float *__restrict__ bias, void *__restrict__ out, GemmAux aux, int pg)
+// XCD-aware tile order of one region of the tile space (`nblk` workgroups = `panels` row panels x `gn` column tiles of
+// `bnt` columns): blocks that share an XCD (same id mod 8) walk a contiguous range; inside it, groups of `pg` row
+// panels, column-major inside a group, so the ~32 tiles an XCD runs at once share few A panels AND few W tiles (their
+// union has to fit its 4 MiB L2; row-major order with 12 column tiles touches all of W every round and re-fetches it:
+// 139 MB vs 24 MB of operands)
+__device__ __forceinline__ void decode_tile256(int bid, int nblk, int gn, int panels, int pg, int bnt, int &m0, int &n0)
 {
-    static_assert(NIW == 3 || NIW == 4, "tile width 192 or 256");
-    constexpr int BNT = 64 * NIW;                 // tile columns
+    const int qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
+    bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
+    const int per_group = pg * gn;
+    const int grp = bid / per_group, rem = bid - grp * per_group;
+    const int rows_here = min(pg, panels - grp * pg);
+    m0 = (grp * pg + rem % rows_here) * BM2;
+    n0 = (rem / rows_here) * bnt;
+}
+
+// one output tile [m0, m0+256) x [n0, n0 + 64*NIW); NIW = 2 is the 256x128 "half" tile of the mixed launch below
+template <int EPI, int NIW, bool PATCH>
+__device__ __forceinline__ void gemm256_tile(
+    const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
+    const float *__restrict__ bias, void *__restrict__ out, const GemmAux &aux, const int m0, const int n0, char *smem)
+{
+    static_assert(NIW >= 2 && NIW <= 4, "tile width 128, 192 or 256");
     constexpr int WCOLS = 16 * NIW;               // columns per wave
-    constexpr int W1_LOADS = NIW == 4 ? 2 : 1;    // global_load_lds per wave for piece W1 (128 or 64 rows)
+    constexpr int W1_LOADS = NIW == 4 ? 2 : (NIW == 3 ? 1 : 0);    // global_load_lds per wave for piece W1 (128, 64 or 0 rows)
     constexpr int W_LOADS = 2 + W1_LOADS;         // ... for W0 + W1: the queue depth the counted wait leaves
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-
-    const int gn = N / BNT;
-    const int nblk = gridDim.x;
-    int bid = blockIdx.x;
-    {
-        const int qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7;
-        bid = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + (bid >> 3);
-    }
-    // Tile order inside an XCD's contiguous range: groups of `pg` row panels, column-major inside a group, so the
-    // ~32 tiles an XCD runs at once share few A panels AND few W tiles (their union has to fit its 4 MiB L2;
-    // row-major order with N/BNT = 12 touches all of W every round and re-fetches it: 139 MB vs 24 MB of operands)
-    const int per_group = pg * gn;
-    const int grp = bid / per_group, rem = bid - grp * per_group;
-    const int rows_here = min(pg, M / BM2 - grp * pg);
-    const int m0 = (grp * pg + rem % rows_here) * BM2;
-    const int n0 = (rem / rows_here) * BNT;
 
     // ---- staging: a 128-row piece is 16 blocks of 8 rows (1 KiB each); wave w issues blocks 2w, 2w+1.
     // The 64-row W1 of the 192-wide tile is 8 blocks, one per wave.
     const int rr = lane >> 3;
     const int sc = (lane & 7) ^ rr;
-    const bf16_t *a_src = A + (size_t)(m0 + wave * 16 + rr) * K + sc * 8;   // + half*128 rows, + 8 rows, + kt*64
+    // Staging addresses = wave-uniform base (tile, piece, K-tile: SGPRs) + ONE per-lane 32-bit byte offset that never
+    // changes (row rr of the 8-row block, swizzled source chunk sc): the loads take the saddr + voffset form, so no 64-bit
+    // per-lane pointers live across the main loop (fewer VGPRs in a kernel that runs against the 256-register budget)
+    const uint32_t lane_off = (uint32_t)((rr * K + sc * 8) * 2);
     // PATCH: the four A rows this lane stages per K-tile (half 0/1 x rows +0/+8) as pixel addresses.  K-tile kt covers
     // channel kt/16, patch rows ky = 2*(kt%16) and +1; source chunk sc is kx = 8*(sc&3) .. +7 of row ky + (sc>>2)
     // -- the same 16 contiguous bytes im2col would have copied.
@@ -361,8 +381,6 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
                 pa[hh][j] = aux.pix + ((size_t)(b * 3) * S + gy * 32) * S + gx * 32 + (sc >> 2) * S + (sc & 3) * 8;
             }
     }
-    const bf16_t *w_src = W + (size_t)(n0 + wave * 16 + rr) * K + sc * 8;
-    const bf16_t *w1_src = W + (size_t)(n0 + 128 + wave * 8 + rr) * K + sc * 8;   // NIW == 3 only
     const int nkt = K / BK;
     // kind: 0 = W0, 1 = W1, 2 = A0, 3 = A1  (the rotating stream order)
     auto stage = [&](int kt, int kind) {
@@ -370,8 +388,10 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         const int half = kind & 1;
         const bool isA = kind >= 2;
         char *dst = smem + (kt & 1) * STAGE2_BYTES + ((isA ? 0 : 2) + half) * HALF_BYTES;
-        if (NIW == 3 && kind == 1) {
-            glds16(w1_src + (size_t)kt * BK, dst + wave * 1024);
+        if (NIW == 2 && kind == 1) return;         // a 128-column tile has no W1 piece
+        if (NIW == 3 && kind == 1) {               // the 64-row W1 of the 192-wide tile: 8 blocks, one per wave
+            const char *b1 = reinterpret_cast<const char *>(W) + ((size_t)(n0 + 128 + wave * 8) * K + (size_t)kt * BK) * 2;
+            glds16(b1 + lane_off, dst + wave * 1024);
             return;
         }
         if (PATCH && isA) {
@@ -380,9 +400,10 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
             glds16(pa[half][1] + off, dst + wave * 2048 + 1024);
             return;
         }
-        const bf16_t *src = (isA ? a_src : w_src) + (size_t)half * 128 * K + (size_t)kt * BK;
-        glds16(src, dst + wave * 2048);
-        glds16(src + (size_t)8 * K, dst + wave * 2048 + 1024);
+        const char *base = reinterpret_cast<const char *>(isA ? A : W) +
+                           ((size_t)((isA ? m0 : n0) + half * 128 + wave * 16) * K + (size_t)kt * BK) * 2;
+        glds16(base + lane_off, dst + wave * 2048);
+        glds16(base + (size_t)16 * K + lane_off, dst + wave * 2048 + 1024);        // 8 rows further
     };
 
     f32x4 acc[NIW][8];  // [ni][mi]
@@ -401,6 +422,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         if constexpr (epi_bias(EPI)) bias4[ni] = *reinterpret_cast<const float4 *>(bias + n0 + wc * WCOLS + ni * 16 + fg * 4);
     }
 
+    MMR_STAMP(blockIdx.x, 0);
     // prologue: stream elements 0..5 = W0,W1,A0,A1 of tile 0 and W0,W1 of tile 1
     float2 *row_stats = reinterpret_cast<float2 *>(smem + GEMM2_LDS);   // LNFOLD only: (mean, rstd) of the BM2 tile rows
     LnfoldLoads ld;
@@ -409,6 +431,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     if (nkt > 1) wait_vmcnt<W_LOADS>(); else wait_vmcnt<0>();
     if constexpr (epi_lnfold(EPI)) lnfold_finish(aux, ld, row_stats);
     __builtin_amdgcn_s_barrier();
+    MMR_STAMP(blockIdx.x, 1);
     // Stagger: waves 4-7 (wr == 1, the SIMD partners of waves 0-3) run one segment behind, so on every
     // SIMD one wave is in a LOAD segment (ds_read + global_load_lds) while its partner is in a COMPUTE
     // segment.  Every wave executes the same number of barriers (compensated after the loop).
@@ -468,6 +491,7 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     }
 #undef MMR_LOAD_DONE
     if (wr == 0) __builtin_amdgcn_s_barrier();
+    MMR_STAMP(blockIdx.x, 2);
 
 #ifdef MMR_GEMM_NOEPI   // diagnostic build: time prologue + main loop only (outputs are wrong)
     {
@@ -595,6 +619,246 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
         to_lds(1);
         store_rows(1, hv1);
     }
+#ifdef MMR_GEMM_STAMPS
+    MMR_STAMP(blockIdx.x, 3);          // epilogue instructions issued (stores may still be in flight)
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------
+// Persistent form of the 256x256 kernel for launches of MORE tiles than CUs with a bf16 epilogue (qkv, fc1: 450 / 600
+// tiles at batch 256).  A tile "round" of the plain kernel is ~20 us of main loop plus ~7 us in which the matrix pipes
+// idle: the epilogue, the drain of its stores, the dispatch of the CU's next workgroup and that workgroup's first
+// operand loads from a cold queue.  Here one workgroup per CU walks tiles b, b + grid, b + 2*grid, ... and
+//   * issues the NEXT tile's prologue loads (six 16 KiB pieces into the staging buffers, idle once the main loop's last
+//     barrier has passed) BEFORE it runs the current tile's epilogue, which works in a separate 4 KiB-per-wave LDS scratch
+//     (four passes of 32 rows) -- so the loads fly during the epilogue;
+//   * never waits for its epilogue stores: the next tile's first counted wait names them as the youngest entries of the
+//     in-order VM queue (s_waitcnt vmcnt(16 stores + W loads)), so they drain under the next tile's first K-steps.
+// Main loop, staging order, swizzles and accumulation order are those of gemm256_tile<EPI, 4>: results are bit-identical.
+// ---------------------------------------------------------------------------------------------
+constexpr int EPI_SCRATCH = 4096;                       // per wave: [32 rows][8 chunks of 8 bf16]
+constexpr int GEMM2P_LDS = GEMM2_LDS + 8 * EPI_SCRATCH; // 160 KiB: the whole LDS of a CU
+constexpr int GEMM2P_STORES = 16;                       // epilogue global stores per wave per tile (4 passes x 4)
+
+template <int EPI>
+__global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_persist_kernel(
+    const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
+    const float *__restrict__ bias, bf16_t *__restrict__ out, int pg, int ntiles)
+{
+    static_assert(epi_bf16(EPI) && !epi_lnfold(EPI), "persistent form: plain bf16 epilogues");
+    constexpr int NIW = 4, WCOLS = 64, W_LOADS = 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int rr = lane >> 3;
+    const int sc = (lane & 7) ^ rr;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int gn = N / 256, panels = M / BM2;
+    const int nkt = K / BK;
+    const int w_row0 = wc * WCOLS;
+    char *scratch = smem + GEMM2_LDS + wave * EPI_SCRATCH;
+
+    // Staging addresses = wave-uniform base (tile, K-tile, piece: SGPRs) + ONE per-lane 32-bit byte offset that never
+    // changes (row rr of the 8-row block, swizzled source chunk sc): the loads take the saddr + voffset form and no
+    // 64-bit per-lane pointer lives across the loop (the 256-VGPR budget is what this kernel runs against)
+    int m0, n0;
+    auto set_tile = [&](int t) { decode_tile256(t, ntiles, gn, panels, pg, 256, m0, n0); };
+    const uint32_t lane_off = (uint32_t)((rr * K + sc * 8) * 2);
+    // kind: 0 = W0, 1 = W1, 2 = A0, 3 = A1 (gemm256_tile's rotating stream order)
+    auto stage = [&](int kt, int kind) {
+        if (kt >= nkt) return;
+        const int half = kind & 1;
+        const bool isA = kind >= 2;
+        char *dst = smem + (kt & 1) * STAGE2_BYTES + ((isA ? 0 : 2) + half) * HALF_BYTES;
+        const char *base = reinterpret_cast<const char *>(isA ? A : W) +
+                           ((size_t)((isA ? m0 : n0) + half * 128 + wave * 16) * K + (size_t)kt * BK) * 2;
+        glds16(base + lane_off, dst + wave * 2048);
+        glds16(base + (size_t)16 * K + lane_off, dst + wave * 2048 + 1024);       // 8 rows further
+    };
+
+    int tile = blockIdx.x;
+    set_tile(tile);
+    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
+    bool first = true;
+#ifdef MMR_GEMM_STAMPS
+    int stamp_slot = blockIdx.x;
+#endif
+    for (;;) {
+        const int cm0 = m0, cn0 = n0;
+        MMR_STAMP(stamp_slot, 0);
+        float4 bias4[NIW];
+#pragma unroll
+        for (int ni = 0; ni < NIW; ++ni) bias4[ni] = *reinterpret_cast<const float4 *>(bias + cn0 + wc * WCOLS + ni * 16 + fg * 4);
+        f32x4 acc[NIW][8];
+#pragma unroll
+        for (int i = 0; i < NIW; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        // K-tile 0's pieces have landed once only these YOUNGER entries remain in the in-order queue: the W pieces of
+        // K-tile 1, (after the first tile) the previous tile's 16 epilogue stores, and the 4 bias loads just issued
+        constexpr int BIAS_LOADS = NIW;
+        if (nkt > 1) { if (first) wait_vmcnt<W_LOADS + BIAS_LOADS>(); else wait_vmcnt<W_LOADS + GEMM2P_STORES + BIAS_LOADS>(); }
+        else { if (first) wait_vmcnt<BIAS_LOADS>(); else wait_vmcnt<GEMM2P_STORES + BIAS_LOADS>(); }
+        __builtin_amdgcn_s_barrier();
+        MMR_STAMP(stamp_slot, 1);
+        if (wr == 1) __builtin_amdgcn_s_barrier();
+
+        bf16x8 af[4][2], wf[NIW][2];
+#define MMR_LOAD_DONE()  do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
+        for (int kt = 0; kt < nkt; ++kt) {
+            const char *sb = smem + (kt & 1) * STAGE2_BYTES;
+            const char *ta = sb + wr * HALF_BYTES;
+            const char *tw = sb + 2 * HALF_BYTES;
+            auto read_w = [&]() {
+#pragma unroll
+                for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        wf[ni][ks] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(w_row0 + ni * 16 + fr, ks * 4 + fg));
+            };
+            auto read_a = [&](int mh) {
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        af[mi][ks] = *reinterpret_cast<const bf16x8 *>(ta + tile_off(mh * 64 + mi * 16 + fr, ks * 4 + fg));
+            };
+            auto mma = [&](int mh) {
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int ni = 0; ni < NIW; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < 4; ++mi)
+                            acc[ni][mh * 4 + mi] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni][ks], af[mi][ks], acc[ni][mh * 4 + mi], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            };
+            read_w(); read_a(0);
+            stage(kt + 1, 2);
+            stage(kt + 1, 3);
+            MMR_LOAD_DONE();
+            mma(0);
+            __builtin_amdgcn_s_barrier();
+            read_a(1);
+            stage(kt + 2, 0);
+            stage(kt + 2, 1);
+            if (kt + 2 < nkt) wait_vmcnt<W_LOADS>(); else wait_vmcnt<0>();
+            MMR_LOAD_DONE();
+            mma(1);
+            __builtin_amdgcn_s_barrier();
+        }
+#undef MMR_LOAD_DONE
+        if (wr == 0) __builtin_amdgcn_s_barrier();
+        MMR_STAMP(stamp_slot, 2);
+        // Every wave is past its last fragment read (they all arrived at the barrier above) and the VM queue is empty (the
+        // last K-tile waited vmcnt(0)).  Touch the bias registers here so that the compiler's own wait for those loads sits
+        // at this point, where it is free -- not in the epilogue, behind the prologue loads issued next.
+#pragma unroll
+        for (int ni = 0; ni < NIW; ++ni) asm volatile("" : "+v"(bias4[ni].x), "+v"(bias4[ni].y), "+v"(bias4[ni].z), "+v"(bias4[ni].w));
+
+        const int next = tile + (int)gridDim.x;
+        const bool more = next < ntiles;
+        if (more) {
+            set_tile(next);
+            stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
+        }
+
+        // ---- epilogue of tile (cm0, cn0): four passes of 32 rows through this wave's private 4 KiB scratch.
+        // The scratch accesses are inline asm on purpose: for C++ LDS accesses hipcc orders every ds_write behind the
+        // pending LDS-DMA of the same __shared__ array with an s_waitcnt vmcnt(0) (checked in the ISA), which would hold
+        // the epilogue until the next tile's prologue loads have landed -- the overlap this kernel exists for.  The
+        // scratch is private to the wave and the LDS executes one wave's operations in order, so a pass needs no wait
+        // between its writes and its reads, nor between its reads and the next pass's writes; only the registers that
+        // receive the reads are waited for (lgkmcnt) before the stores use them.
+        const size_t row_base = (size_t)(cm0 + wr * 128);
+        const int col_base = cn0 + wc * WCOLS;
+        const int rc = lane & 7, rr0 = lane >> 3;
+        const uint32_t sbase = (uint32_t)(uintptr_t)scratch;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+#pragma unroll
+            for (int ni = 0; ni < NIW; ++ni) {
+                const float4 b4 = bias4[ni];
+                const int c = ni * 2 + (fg >> 1);
+#pragma unroll
+                for (int mj = 0; mj < 2; ++mj) {
+                    const f32x4 a = acc[ni][2 * p + mj];
+                    const float v0 = epi_act<EPI>(a[0] + b4.x), v1 = epi_act<EPI>(a[1] + b4.y);
+                    const float v2 = epi_act<EPI>(a[2] + b4.z), v3 = epi_act<EPI>(a[3] + b4.w);
+                    const int row = mj * 16 + fr;
+                    u32x2_t pk;
+                    pk.x = pack_bf16x2(v0, v1);
+                    pk.y = pack_bf16x2(v2, v3);
+                    const uint32_t addr = sbase + row * 128 + ((c ^ (row & 7)) << 4) + (fg & 1) * 8;
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(pk) : "memory");
+                }
+            }
+            u32x4_t rows4[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = i * 8 + rr0;
+                const uint32_t addr = sbase + row * 128 + ((rc ^ (row & 7)) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(rows4[i]) : "v"(addr) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rows4[0]), "+v"(rows4[1]), "+v"(rows4[2]), "+v"(rows4[3])::"memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                epi_store16(out + MMR_OUT_ROW(row_base + p * 32 + i * 8 + rr0) * N + col_base + rc * 8, rows4[i]);
+        }
+#ifdef MMR_GEMM_STAMPS
+        MMR_STAMP(stamp_slot, 3);
+        stamp_slot += 256;
+#endif
+        if (!more) break;
+        tile = next;
+        first = false;
+    }
+}
+
+template <int EPI, int NIW, bool PATCH = false>
+__global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
+    const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
+    const float *__restrict__ bias, void *__restrict__ out, GemmAux aux, int pg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int m0, n0;
+    decode_tile256(blockIdx.x, gridDim.x, N / (64 * NIW), M / BM2, pg, 64 * NIW, m0, n0);
+    gemm256_tile<EPI, NIW, PATCH>(A, W, M, N, K, bias, out, aux, m0, n0, smem);
+}
+
+// Mixed launch for GEMMs whose 256x256 tile count is a bad multiple of the 256 CUs (fc1 at batch 256: 600 tiles = 2.34
+// rounds, run as 3).  The first `ph` row panels are cut into 256x128 HALF tiles and dispatched first, the rest into
+// full tiles: the hardware hands a freed CU the next workgroup, so the CUs that started on a half tile run half a tile
+// time ahead of the others for the rest of the launch.  Two effects: the launch ends after ~2.55 tile times instead of
+// 3, and the two groups' epilogues (an HBM-write burst during which the matrix pipes idle) no longer coincide -- one
+// group stores while the other computes.  Both tile shapes share one kernel so that they share one dispatch queue.
+template <int EPI>
+__global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_mixed_kernel(
+    const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
+    const float *__restrict__ bias, void *__restrict__ out, GemmAux aux, int ph, int pg_half, int pg_full)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n_half = ph * (N / 128);
+    int m0, n0;
+    if ((int)blockIdx.x < n_half) {
+        decode_tile256(blockIdx.x, n_half, N / 128, ph, pg_half, 128, m0, n0);
+        gemm256_tile<EPI, 2, false>(A, W, M, N, K, bias, out, aux, m0, n0, smem);
+    } else {
+        decode_tile256(blockIdx.x - n_half, gridDim.x - n_half, N / 256, M / BM2 - ph, pg_full, 256, m0, n0);
+        gemm256_tile<EPI, 4, false>(A, W, M, N, K, bias, out, aux, m0 + ph * BM2, n0, smem);
+    }
+}
+
+static int tile_group_panels(int gn)
+{
+    // panels per tile-order group: the concurrent set of one XCD (32 CUs) should be near-square, at most 6 columns wide
+    static const int force_pg = getenv("MMR_GEMM_PG") ? atoi(getenv("MMR_GEMM_PG")) : 0;
+    const int cols = gn < 6 ? gn : 6;
+    return force_pg > 0 ? force_pg : (32 + cols - 1) / cols;
 }
 
 template <int EPI, int NIW, bool PATCH = false>
@@ -606,15 +870,104 @@ static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K,
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_bf16_kernel<EPI, NIW, PATCH>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS + BM2 * 8));
     }
-    // panels per tile-order group: the concurrent set of one XCD (32 CUs) should be near-square, at most 6 columns wide
-    static const int force_pg = getenv("MMR_GEMM_PG") ? atoi(getenv("MMR_GEMM_PG")) : 0;
     const int gn = N / (64 * NIW);
-    const int cols = gn < 6 ? gn : 6;
-    const int pg = force_pg > 0 ? force_pg : (32 + cols - 1) / cols;
+    const int pg = tile_group_panels(gn);
     hipLaunchKernelGGL((gemm256_bf16_kernel<EPI, NIW, PATCH>), dim3((M / BM2) * gn), dim3(GEMM2_THREADS),
                        GEMM2_LDS + BM2 * 8, st, A, W, M, N, K, bias, out, aux, pg);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
+}
+
+template <int EPI>
+static int launch_gemm256_mixed(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
+                                const GemmAux &aux, int ph, hipStream_t st)
+{
+    static DeviceOnce once;
+    if (once.first()) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_mixed_kernel<EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS + BM2 * 8));
+    }
+    const int panels = M / BM2;
+    const int grid = ph * (N / 128) + (panels - ph) * (N / 256);
+    hipLaunchKernelGGL((gemm256_mixed_kernel<EPI>), dim3(grid), dim3(GEMM2_THREADS), GEMM2_LDS + BM2 * 8, st, A, W, M, N, K,
+                       bias, out, aux, ph, tile_group_panels(N / 128), tile_group_panels(N / 256));
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+template <int EPI>
+static int launch_gemm256_persist(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
+                                  hipStream_t st)
+{
+    static DeviceOnce once;
+    if (once.first()) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_persist_kernel<EPI>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
+    }
+    const int ntiles = (M / BM2) * (N / 256);
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL((gemm256_persist_kernel<EPI>), dim3(grid), dim3(GEMM2_THREADS), GEMM2P_LDS, st, A, W, M, N, K, bias,
+                       (bf16_t *)out, tile_group_panels(N / 256), ntiles);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+// Row panels to cut into half tiles (gemm256_mixed_kernel) for an M x N problem on 256x256 tiles, from greedy list
+// scheduling of [ph*2*gn half tiles, then (panels-ph)*gn full tiles] over the CUs with a half tile costing HALF_COST of a
+// full one.  Calibrated on MI355X against a sweep of ph (tools/sweep_half_panels.sh, ViT-B/32 batch 256):
+//   fc1 12800x3072x768 (600 tiles = 2.34 rounds): plain 77.2 us; ph = 8 / 10 / 12: 74.6 / 73.4 / 73.5; ph = 16: 84.1
+//   qkv 12800x2304x768 (450 tiles = 1.76 rounds): plain 49.1 us; ph = 4 / 6: 47.7 / 47.8; ph >= 8 (third round): 58-60
+// The model's round structure is sharper than the hardware's (a thinly occupied last round runs its tiles faster), so it
+// over-predicts the gain (fc1: 68 us) but ranks the candidates right with HALF_COST 0.65: take the MIDDLE of the
+// minimum-makespan range -- also when that minimum only ties the plain launch, because the stagger alone is worth 3 % (qkv).
+// Long launches (> 4 rounds: ViT-L/14) measured within +-1 % either way and stay plain.
+static int mixed_half_panels(int panels, int gn)
+{
+    static const int forced = getenv("MMR_GEMM_HALF_PANELS") ? atoi(getenv("MMR_GEMM_HALF_PANELS")) : -1;   // A/B aid
+    if (forced >= 0) return forced < panels ? forced : panels;
+    static const double half_cost = getenv("MMR_GEMM_HALF_COST") ? atof(getenv("MMR_GEMM_HALF_COST")) : 0.65;
+    const int cus = 256;
+    if ((long long)panels * gn > 4LL * cus) return 0;
+    auto makespan = [&](int ph) {
+        // every CU free at 0; tiles are taken in launch order by the earliest-free CU (a binary min-heap of free times)
+        double heap[256];
+        for (int i = 0; i < cus; ++i) heap[i] = 0.0;
+        auto pop_push = [&](double cost) {        // replace the minimum by minimum + cost, restore the heap
+            heap[0] += cost;
+            int i = 0;
+            for (;;) {
+                int l = 2 * i + 1, r = l + 1, m = i;
+                if (l < cus && heap[l] < heap[m]) m = l;
+                if (r < cus && heap[r] < heap[m]) m = r;
+                if (m == i) break;
+                const double t = heap[i]; heap[i] = heap[m]; heap[m] = t;
+                i = m;
+            }
+        };
+        const int n_half = ph * 2 * gn, n_full = (panels - ph) * gn;
+        for (int i = 0; i < n_half; ++i) pop_push(half_cost);
+        for (int i = 0; i < n_full; ++i) pop_push(1.0);
+        double mx = 0.0;
+        for (int i = 0; i < cus; ++i) mx = heap[i] > mx ? heap[i] : mx;
+        return mx;
+    };
+    struct Memo { int panels, gn, ph; };
+    static thread_local Memo memo[8];
+    static thread_local int memo_n = 0;
+    for (int i = 0; i < memo_n; ++i)
+        if (memo[i].panels == panels && memo[i].gn == gn) return memo[i].ph;
+    // the minimum-makespan candidates form a range [lo, hi]; its ends sit next to a different round count, so take the middle
+    double best_t = makespan(0);
+    int lo = 0, hi = 0;
+    for (int ph = 1; ph <= panels / 2; ++ph) {
+        const double t = makespan(ph);
+        if (t < best_t - 1e-9) { best_t = t; lo = hi = ph; }
+        else if (t <= best_t + 1e-9) hi = ph;
+    }
+    if (lo == 0 && hi > 0) lo = 1;
+    const int best = (lo + hi + 1) / 2;
+    if (memo_n < 8) memo[memo_n++] = Memo{panels, gn, best};
+    return best;
 }
 
 template <int EPI, int NSTG>
@@ -823,6 +1176,28 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
             case EPI_BIAS_TANH_BF16: return launch_gemm_skinny<EPI_BIAS_TANH_BF16>(A, W, M, N, K, bias, out, st);
         }
     }
+    // 256x256 tiles whose count is a bad multiple of the CU count: mixed half/full launch (gemm256_mixed_kernel); built
+    // for the two epilogues of the wide-N projections (qkv, fc1)
+    // MMR_GEMM_PERSIST=1 routes multi-round bf16-epilogue launches to gemm256_persist_kernel.  Off by default: measured on
+    // MI355X it removes the ~2 us workgroup turnaround and half of the 1.4 us prologue wait per tile, but its main loop runs
+    // 0.8 us per tile slower beside the draining stores: ViT-B/32 qkv 48.6 us either way, fc1 76.3 vs 71.4 us for the mixed
+    // launch, ViT-L/14 fc1 549 vs 555 us ("where a GEMM tile's time goes")
+    static const int persist = getenv("MMR_GEMM_PERSIST") ? atoi(getenv("MMR_GEMM_PERSIST")) : 0;
+    if (persist && tile == 256 && (long long)(M / BM2) * (N / 256) > 256) {
+        switch (epi) {
+            case EPI_BIAS_BF16: return launch_gemm256_persist<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
+            case EPI_BIAS_GELU_BF16: return launch_gemm256_persist<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);
+            case EPI_BIAS_GELU_ERF_BF16: return launch_gemm256_persist<EPI_BIAS_GELU_ERF_BF16>(A, W, M, N, K, bias, out, st);
+            default: break;
+        }
+    }
+    if (tile == 256 && (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16)) {
+        const int ph = mixed_half_panels(M / BM2, N / 256);
+        if (ph > 0) {
+            return epi == EPI_BIAS_BF16 ? launch_gemm256_mixed<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, aux, ph, st)
+                                        : launch_gemm256_mixed<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, aux, ph, st);
+        }
+    }
 #define MMR_GEMM_CASE(E)                                                                                   \
     case E: return tile == 256   ? launch_gemm256<E, 4>(A, W, M, N, K, bias, out, aux, st)                 \
                    : tile == 192 ? launch_gemm256<E, 3>(A, W, M, N, K, bias, out, aux, st)                 \
@@ -859,6 +1234,23 @@ int launch_gemm_patch32(const bf16_t *pix, int B, int S, const bf16_t *W, int M,
     if (c192 > 0 && (c256 < 0 || c192 < c256)) return launch_gemm256<EPI_STORE_F32, 3, true>(nullptr, W, M, N, K, nullptr, out, aux, st);
     return launch_gemm256<EPI_STORE_F32, 4, true>(nullptr, W, M, N, K, nullptr, out, aux, st);
 }
+
+#ifdef MMR_GEMM_STAMPS
+}  // namespace mmr
+extern "C" int mmr_debug_gemm_stamps(unsigned long long *host_out, int clear)
+{
+    using namespace mmr;
+    if (host_out) MMR_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mmr_stamp_buf), sizeof(unsigned long long) * 8192 * 4));
+    if (host_out) MMR_CHECK_HIP(hipMemcpyFromSymbol(host_out + 8192 * 4, HIP_SYMBOL(mmr_cycle_buf), sizeof(unsigned long long) * 8192 * 4));
+    if (clear) {
+        void *p = nullptr;
+        MMR_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(mmr_stamp_buf)));
+        MMR_CHECK_HIP(hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 4));
+    }
+    return MMR_OK;
+}
+namespace mmr {
+#endif
 
 int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
                 hipStream_t st)

@@ -51,7 +51,9 @@ def _check_cos(got, want, what, fold=False):
                                    (12800, 1024, 128),      # 256x256 tiles
                                    (33024, 256, 64),        # 129 tiles: workgroup count not a multiple of the 8 XCDs
                                    (11008, 768, 64),        # 43 row panels x 4: ragged last tile-order group
-                                   (35840, 512, 128),       # 280 tiles, 2 per panel: more than one round
+                                   (35840, 512, 128),       # 280 tiles, 2 per panel: more than one round (mixed half/full launch for the bf16 epilogues)
+                                   (12800, 3072, 768), (12800, 2304, 768),  # fc1 / qkv at batch 256: 600 / 450 tiles -> mixed half/full launch
+                                   (9216, 1024, 64),        # 36 panels x 4: mixed launch with a ragged half-tile group
                                    (2304, 384, 128), (3072, 768, 3072),     # 128x128 tiles (M > 2048, too few 256-row tiles)
                                    (2048, 128, 64), (128, 3072, 768)])      # 128x32 tiles at both ends of their range
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6])
