@@ -25,6 +25,7 @@
 
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace mmr {
 
@@ -466,6 +467,213 @@ __global__ __launch_bounds__(ScanF32Cfg<E>::SCAN_THREADS, ScanF32Cfg<E>::SCAN_WA
             pend_tile = t;
         }
         cur = cur + 1 >= SCAN_NBUF ? 0 : cur + 1;
+    }
+    if (compute && g == 0) {
+        if (pend_tile >= 0) bmax[(size_t)pend_tile * qpad + wave * 16 + r] = pend;
+        tmax[(size_t)task * qpad + wave * 16 + r] = task_max;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan for fp32 galleries at the bf16 MFMA rate: split-bf16.  Every fp32 value x is split into hi = bf16(x) and
+// lo = bf16(x - hi) (x = hi + lo up to 2^-18 |x|) and the dot product is accumulated as q_hi.g_hi + q_lo.g_hi + q_hi.g_lo
+// on v_mfma_f32_16x16x32_bf16 -- three MFMAs per 32-deep k-step instead of the eight v_mfma_f32_16x16x4_f32 (1/16 of the
+// bf16 rate) scan_f32_kernel needs.  Error of the approximate dot against the exact one: dropped q_lo.g_lo and the two
+// representation residuals, 3 * 2^-18 |q||g| = 1.1e-5, plus fp32 accumulation ~5e-6: well inside the certificate's
+// 8e-5 |q||g| margin, and the ranking itself is still done on exact fp64 re-scores.
+// Per 16-row tile: the fp32 rows arrive by global_load_lds (ring of NBUF tiles); ALL waves then split the tile ONCE into
+// two bf16 images (hi, lo; 24 VALU instructions per 8 values -- done per consuming wave instead, the conversion was 8x
+// redundant and the kernel VALU-bound: 0.78 ms for 1M x 512 x 128 queries); the computing waves read their A fragments
+// from those images exactly like scan16_kernel (conflict-free ds_read_b128, prefetched with counted lgkmcnt waits).
+// Each wave keeps 16 queries resident as hi/lo B fragments.
+//   conversion unit (row = id & 15, cg = id >> 4): fp32 chunks 4cg .. 4cg+3 of the row -> bf16 chunks 2cg, 2cg+1 of both
+//   images; a 16-lane group works on 16 different rows at one chunk index, so slot = (chunk ^ row) & 15 is a bijection
+//   for its reads and its writes.
+// ---------------------------------------------------------------------------------------------
+template <int E>
+struct ScanF32sCfg {
+    static constexpr int SCAN_WAVES = E <= 512 ? 8 : 4;    // E = 768: 192 VGPRs of resident queries -> one wave per SIMD
+    static constexpr int SCAN_THREADS = SCAN_WAVES * 64;
+    static constexpr int QMAX = SCAN_WAVES * 16;
+    static constexpr int NBUF = E <= 512 ? 3 : 2;          // fp32 tiles in the ring (E = 768: 48 KiB each)
+    static constexpr int CH = E / 4;                       // 16-byte chunks per fp32 row
+    static constexpr int ROWB = E * 4;
+    static constexpr int TILE_BYTES = TILE_ROWS_F32 * ROWB;
+    static constexpr int LOADS = TILE_ROWS_F32 * CH / 64;
+    static constexpr int LPW = LOADS / SCAN_WAVES;
+    static constexpr int KSTEPS = E / 32;
+    static constexpr int CHB = E / 8;                      // 16-byte chunks per bf16 image row
+    static constexpr int IMG_BYTES = TILE_ROWS_F32 * E * 2;// one bf16 image (hi or lo)
+    static constexpr int UNITS = TILE_ROWS_F32 * (E / 16); // conversion units per tile
+    static constexpr int LDS = NBUF * TILE_BYTES + 2 * IMG_BYTES;     // E = 512: 96 + 32 KiB
+    static_assert(LOADS % SCAN_WAVES == 0 && CH % 16 == 0 && CHB % 16 == 0, "tile geometry");
+};
+
+// 8 fp32 -> hi and lo bf16 fragments (24 VALU instructions)
+__device__ __forceinline__ void split_bf16x8(const float4 &a0, const float4 &a1, bf16x8 &hi, bf16x8 &lo)
+{
+    const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    union { bf16x8 v; uint32_t u[4]; } h, l;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        h.u[j] = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+        const float r0 = x[2 * j] - __uint_as_float(h.u[j] << 16);
+        const float r1 = x[2 * j + 1] - __uint_as_float(h.u[j] & 0xffff0000u);
+        l.u[j] = pack_bf16x2(r0, r1);
+    }
+    hi = h.v;
+    lo = l.v;
+}
+
+template <int E>
+__global__ __launch_bounds__(ScanF32sCfg<E>::SCAN_THREADS, ScanF32sCfg<E>::SCAN_WAVES / 4) void scan_f32s_kernel(
+    const float *__restrict__ q, const float *__restrict__ gal, int Q, int64_t N, int ntiles, int tpt, int qwaves,
+    int qpad, float *__restrict__ bmax, float *__restrict__ tmax)
+{
+    using C = ScanF32sCfg<E>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *img = smem + C::NBUF * C::TILE_BYTES;          // [hi | lo] bf16 images of the tile being multiplied
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int task = blockIdx.x;
+    const int t0 = task * tpt;
+    const int t1 = min(ntiles, t0 + tpt);
+    const bool compute = wave < qwaves;
+
+    bf16x8 bqh[C::KSTEPS], bql[C::KSTEPS];     // query (wave*16 + r), elements [32s + 8g, +8), split
+    {
+        const int qrow = wave * 16 + r;
+        const bool live = compute && qrow < Q;
+        const float *qp = q + (size_t)(live ? qrow : 0) * E + g * 8;
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            float4 a0 = *reinterpret_cast<const float4 *>(qp + s * 32), a1 = *reinterpret_cast<const float4 *>(qp + s * 32 + 4);
+            if (!live) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
+            split_bf16x8(a0, a1, bqh[s], bql[s]);
+        }
+    }
+    auto stage = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < C::LPW; ++i) {
+            const int instr = wave * C::LPW + i;
+            const int p = instr * 64 + lane;
+            const int row = p / C::CH;
+            const int pos = p % C::CH;
+            const int chunk = (pos & ~15) | ((pos ^ row) & 15);
+            int64_t grow = (int64_t)tile * TILE_ROWS_F32 + row;
+            grow = grow < N ? grow : N - 1;
+            glds16(gal + grow * E + chunk * 4, smem + buf * C::TILE_BYTES + instr * 1024);
+        }
+    };
+    float task_max = -INFINITY, pend = -INFINITY;
+    int pend_tile = -1;
+
+    // split the fp32 tile in ring slot `slot` into the hi / lo bf16 images `im`, once for the whole workgroup.  The LDS
+    // accesses are inline asm: for C++ accesses hipcc orders them behind the LDS-DMA in flight with s_waitcnt vmcnt(0)
+    // (seen in the ISA), which would expose one HBM latency per tile.
+    auto convert = [&](int slot, int im) {
+        typedef float f32x4_raw __attribute__((ext_vector_type(4)));
+        const uint32_t tf = (uint32_t)(uintptr_t)(smem + slot * C::TILE_BYTES);
+        const uint32_t ih = (uint32_t)(uintptr_t)(img + im * 2 * C::IMG_BYTES), il = ih + C::IMG_BYTES;
+#pragma unroll
+        for (int u = threadIdx.x; u < C::UNITS; u += C::SCAN_THREADS) {
+            const int row = u & 15, cg = u >> 4;
+            f32x4_raw x[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = 4 * cg + j;
+                const uint32_t a = tf + row * C::ROWB + (((c & ~15) | ((c ^ row) & 15)) << 4);
+                asm volatile("ds_read_b128 %0, %1" : "=v"(x[j]) : "v"(a));
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8 hi, lo;
+                split_bf16x8(make_float4(x[2 * j][0], x[2 * j][1], x[2 * j][2], x[2 * j][3]),
+                             make_float4(x[2 * j + 1][0], x[2 * j + 1][1], x[2 * j + 1][2], x[2 * j + 1][3]), hi, lo);
+                const int cb = 2 * cg + j;
+                const uint32_t off = row * (E * 2) + (((cb & ~15) | ((cb ^ row) & 15)) << 4);
+                asm volatile("ds_write_b128 %0, %1" ::"v"(ih + off), "v"(hi) : "memory");
+                asm volatile("ds_write_b128 %0, %1" ::"v"(il + off), "v"(lo) : "memory");
+            }
+        }
+    };
+    // bucket maximum of tile t from the images `im` (computing waves)
+    auto compute_tile = [&](int t, int im) {
+        const char *img_hi = img + im * 2 * C::IMG_BYTES, *img_lo = img_hi + C::IMG_BYTES;
+        const int rowoff = r * (E * 2);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc3 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        // hi / lo A fragments run PF k-steps ahead of the MFMAs through inline-asm reads with counted waits (scan_kernel)
+        constexpr int PF = C::KSTEPS < 3 ? C::KSTEPS : 3;     // deeper (6) measured no faster
+        bf16x8 fh[PF], fl[PF];
+        auto issue = [&](int s, bf16x8 &dh, bf16x8 &dl) {
+            const int c = 4 * s + g;
+            const int off = rowoff + (((c & ~15) | ((c ^ r) & 15)) << 4);
+            const uint32_t ah = (uint32_t)(uintptr_t)(img_hi + off), al = (uint32_t)(uintptr_t)(img_lo + off);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dh) : "v"(ah));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dl) : "v"(al));
+        };
+#pragma unroll
+        for (int s = 0; s < PF && s < C::KSTEPS; ++s) issue(s, fh[s], fl[s]);
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            const int younger_s = (C::KSTEPS - 1 - s) < (PF - 1) ? (C::KSTEPS - 1 - s) : (PF - 1);
+            bf16x8 &ah = fh[s % PF], &al = fl[s % PF];
+            if (younger_s == 5) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(ah), "+v"(al));
+            else if (younger_s == 4) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ah), "+v"(al));
+            else if (younger_s == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ah), "+v"(al));
+            else if (younger_s == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah), "+v"(al));
+            else if (younger_s == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah), "+v"(al));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al));
+            // three accumulation chains (hi.hi, lo.hi, hi.lo): no MFMA waits on the one issued just before it
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bqh[s], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bqh[s], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bql[s], acc3, 0, 0, 0);
+            if (s + PF < C::KSTEPS) {
+                // the MFMAs above must have READ the fragments before the refill overwrites them
+                asm volatile("" : "+v"(acc), "+v"(acc2), "+v"(acc3));
+                issue(s + PF, ah, al);
+            }
+        }
+        // acc[i] (+ acc2 + acc3) = dot(query r, tile row 4*g + i)
+        float m = -INFINITY;
+        const int64_t base = (int64_t)t * TILE_ROWS_F32 + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m = fmaxf(m, base + i < N ? acc[i] + (acc2[i] + acc3[i]) : -INFINITY);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        task_max = fmaxf(task_max, m);
+        pend = m;
+        pend_tile = t;
+    };
+    auto flush_pending = [&]() {
+        if (compute && pend_tile >= 0 && g == 0) bmax[(size_t)pend_tile * qpad + wave * 16 + r] = pend;
+    };
+
+    {
+        // split, barrier, multiply: two barriers per tile.  A second image pair with tile t+1 split while tile t is multiplied
+        // (one barrier per tile, also with the two waves of a SIMD taking the two jobs in opposite orders) measured no faster:
+        // 0.62 vs 0.60 ms for 1M x 512 x 128 queries -- and needs the whole 160 KiB of LDS at E = 512.
+        constexpr int PD = C::NBUF - 1;
+#pragma unroll
+        for (int i = 0; i < PD; ++i)
+            if (t0 + i < t1) stage(t0 + i, i);
+        int cur = 0;
+        for (int t = t0; t < t1; ++t) {
+            const int younger = min(PD - 1, t1 - 1 - t);
+            if (younger >= 1) wait_vmcnt<C::LPW>(); else wait_vmcnt<0>();
+            // tile t has landed for every wave, and every wave is done reading the bf16 images of tile t-1
+            __builtin_amdgcn_s_barrier();
+            flush_pending();
+            int nxt = cur + PD; nxt = nxt >= C::NBUF ? nxt - C::NBUF : nxt;
+            if (t + PD < t1) stage(t + PD, nxt);
+            convert(cur, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // the images are complete
+            if (compute) compute_tile(t, 0);
+            cur = cur + 1 >= C::NBUF ? 0 : cur + 1;
+        }
     }
     if (compute && g == 0) {
         if (pend_tile >= 0) bmax[(size_t)pend_tile * qpad + wave * 16 + r] = pend;
@@ -1289,6 +1497,24 @@ static int launch_scan_f32(const float *q, const float *gal, int Qc, int64_t N, 
     return MMR_OK;
 }
 
+template <int E>
+static int launch_scan_f32s(const float *q, const float *gal, int Qc, int64_t N, const SearchPlan &p, int qpad,
+                            float *bmax, float *tmax, hipStream_t st)
+{
+    ProfScope prof(MMR_PROF_SCAN, st);
+    using C = ScanF32sCfg<E>;
+    const int lds = C::LDS;
+    static DeviceOnce once;
+    if (once.first()) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_f32s_kernel<E>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    hipLaunchKernelGGL(scan_f32s_kernel<E>, dim3(p.ntasks), dim3(C::SCAN_THREADS), lds, st, q, gal, Qc, N, p.ntiles, p.tpt,
+                       qpad / 16, qpad, bmax, tmax);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
 template <typename T, int PER>
 static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, const SearchPlan &p, int qpad,
                            const float *bmax, const float *tmax, float scale, float eps_rel, float host_bound,
@@ -1433,11 +1659,22 @@ static int cosine_topk_impl(const void *q, const void *gallery, mmr_dtype dtype,
                     } break;
                 }
             } else {
-                switch (E) {
-                    case 128: rc = launch_scan_f32<128>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                    case 256: rc = launch_scan_f32<256>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                    case 512: rc = launch_scan_f32<512>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                    default: rc = launch_scan_f32<768>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                // MMR_SCAN_F32=exact keeps the fp32-MFMA scan (exact fma chain, 1/16 of the bf16 rate) for A/B comparisons
+                static const bool exact_f32 = getenv("MMR_SCAN_F32") && !strcmp(getenv("MMR_SCAN_F32"), "exact");
+                if (exact_f32) {
+                    switch (E) {
+                        case 128: rc = launch_scan_f32<128>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                        case 256: rc = launch_scan_f32<256>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                        case 512: rc = launch_scan_f32<512>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                        default: rc = launch_scan_f32<768>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    }
+                } else {
+                    switch (E) {
+                        case 128: rc = launch_scan_f32s<128>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                        case 256: rc = launch_scan_f32s<256>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                        case 512: rc = launch_scan_f32s<512>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                        default: rc = launch_scan_f32s<768>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
+                    }
                 }
             }
             if (rc != MMR_OK) return rc;
