@@ -89,6 +89,23 @@ int mmr_l2norm_rows(void *x, mmr_dtype dtype, int64_t rows, int E, void *stream)
 int mmr_topk_merge(const int64_t *idx_parts, const double *dot_parts, int parts, int Q, int k, float scale,
                    int64_t *idx, float *score, double *dot64, void *stream);
 
+/* Multi-GPU leg for hosts without torch.distributed: one process per GPU; rank r searches its
+ * gallery rows with mmr_cosine_topk(_ex), adds its row offset to the ids (int64, -1 stays -1), then ONE RCCL all-gather
+ * over xGMI of the per-shard (id, fp64 dot) lists and mmr_topk_merge.  librccl is bound at run time (dlopen; MMR_RCCL_LIB
+ * overrides the name), so a single-GPU user needs no RCCL.  The Python package performs the same exchange through
+ * torch.distributed's "nccl" (= RCCL) backend (search.ShardedGalleryIndex). */
+typedef struct mmr_comm mmr_comm;
+#define MMR_COMM_ID_BYTES 128
+/* rank 0: fill MMR_COMM_ID_BYTES bytes of HOST memory; the host program hands them to every rank (file, socket, MPI ...) */
+int mmr_comm_unique_id(void *id_host);
+/* collective over all ranks; binds the communicator to the calling thread's current HIP device */
+int mmr_comm_init(int rank, int world, const void *id_host, mmr_comm **out);
+void mmr_comm_destroy(mmr_comm *c);
+/* idx_local / dot_local [Q,k] (device) -> idx_parts / dot_parts [world,Q,k] (device), asynchronous on `stream`;
+ * the two arrays travel as one fused collective.  Feed the result to mmr_topk_merge(parts = world). */
+int mmr_allgather_topk(mmr_comm *c, const int64_t *idx_local, const double *dot_local, int Q, int k,
+                       int64_t *idx_parts, double *dot_parts, void *stream);
+
 /* Tip-Adapter logits, fused (replaces reference code/main_custom.py:111,124-127 and
  * code/utils.py:182-186):  tip = 100*F@W + alpha * (exp(-(beta - beta*(F@Kc))) @ V * 10).
  *   features[N,E]; clip_weights_t[C,E] = W^T; cache_keys_t[S,E] = Kc^T (all `dtype`);

@@ -63,6 +63,14 @@ def lib():
     L.mmr_l2norm_rows.argtypes = [vp, i32, i64, i32, vp]
     L.mmr_topk_merge.restype = i32
     L.mmr_topk_merge.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
+    L.mmr_comm_unique_id.restype = i32
+    L.mmr_comm_unique_id.argtypes = [vp]
+    L.mmr_comm_init.restype = i32
+    L.mmr_comm_init.argtypes = [i32, i32, vp, ctypes.POINTER(vp)]
+    L.mmr_comm_destroy.restype = None
+    L.mmr_comm_destroy.argtypes = [vp]
+    L.mmr_allgather_topk.restype = i32
+    L.mmr_allgather_topk.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     L.mmr_tip_adapter_logits.restype = i32
     L.mmr_tip_adapter_logits.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, i32, f32, f32, vp, vp, vp]
     L.mmr_preprocess_image.restype = i32

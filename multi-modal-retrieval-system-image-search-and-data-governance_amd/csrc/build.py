@@ -11,7 +11,7 @@ import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api_common.cpp", "search.hip", "gemm.hip", "vit_ops.hip", "tower.hip", "preprocess.hip"]
+SOURCES = ["api_common.cpp", "comm.cpp", "search.hip", "gemm.hip", "vit_ops.hip", "tower.hip", "preprocess.hip"]
 LIB = os.path.join(HERE, "libmmr_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip",
@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         rebuilt = list(ex.map(compile_one, srcs))
     objs = [_obj(s) for s in srcs]
     if force or any(rebuilt) or _stale(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]
         if verbose:
             print("[mmr build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -361,3 +361,35 @@ def test_sharded_index_over_rccl(S, oracle, device):
         assert np.array_equal(torch.cat([o[1] for o in outs]).cpu().numpy(), oi)
     finally:
         dist.destroy_process_group()
+
+
+def test_c_abi_rccl_allgather_of_topk(S, oracle, device):
+    """The non-Python host's multi-GPU leg (include/mmr.h: mmr_comm_* + mmr_allgather_topk): a one-rank RCCL
+    communicator built through the C ABI gathers this rank's (global id, fp64 dot) lists and mmr_topk_merge ranks them --
+    the same result as the local search.  (More ranks need more GPUs; the exchange itself is rank-count agnostic.)"""
+    import ctypes
+    from mmr_amd import _lib
+    L = _lib.lib()
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(L.mmr_comm_unique_id(uid))
+    comm = ctypes.c_void_p()
+    _lib.check(L.mmr_comm_init(0, 1, uid, ctypes.byref(comm)))
+    try:
+        gal = synth.synth_unit_rows(9000, 512, seed=71).bfloat16()
+        q = synth.synth_unit_rows(12, 512, seed=72).bfloat16()
+        _, lidx, ldot = S.cosine_topk(q.to(device), gal.to(device), 10, return_dot64=True)
+        offset = 1_000_000
+        gidx = (lidx + offset).contiguous()
+        ip = torch.empty(1, 12, 10, dtype=torch.int64, device=device)
+        dp = torch.empty(1, 12, 10, dtype=torch.float64, device=device)
+        _lib.check(L.mmr_allgather_topk(comm, gidx.data_ptr(), ldot.data_ptr(), 12, 10, ip.data_ptr(), dp.data_ptr(),
+                                        _lib.stream_ptr(device)))
+        torch.cuda.synchronize(device)
+        assert torch.equal(ip[0], gidx) and torch.equal(dp[0], ldot)
+        score, idx, d64 = S.merge_topk(ip, dp, 100.0)
+        oi, os_, od = oracle.cosine_topk(q, gal, 10, 100.0)
+        assert np.array_equal((idx - offset).cpu().numpy(), oi) and np.array_equal(d64.cpu().numpy(), od)
+        assert np.array_equal(score.cpu().numpy(), os_)
+        assert L.mmr_allgather_topk(None, gidx.data_ptr(), ldot.data_ptr(), 12, 10, ip.data_ptr(), dp.data_ptr(), 0) == -22
+    finally:
+        L.mmr_comm_destroy(comm)

@@ -1,38 +1,58 @@
-"""Latency of small-batch encode (the reference's build_cache loop runs batch 1): eager launches vs hipGraph replay."""
-import sys, os, time
+"""Latency of small-batch calls -- the reference's own call pattern is batch 1 (build_cache, reference
+code/search_image.py:153-158) and batch ~10 (outlier_filter, :305-316): eager launches vs hipGraph replay, for
+encode_image alone and for encode_image + top-10 search over a gallery, replay checked bit-identical to eager.
+Prints one JSON object (profiles/r02_small_batch_latency.json)."""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import mmr_amd
+from mmr_amd import search, synth
 
 dev = torch.device("cuda:0")
-model, _ = mmr_amd.load("ViT-B/32", device=dev, weights="synthetic")
-for B in [int(x) for x in os.environ.get("BS", "1,8,32,64").split(",")]:
-    px = torch.randn(B, 3, 224, 224, device=dev)
-    for _ in range(3):
-        model.encode_image(px)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n = 30
-    for _ in range(n):
-        f = model.encode_image(px)
-    torch.cuda.synchronize()
-    eager = (time.perf_counter() - t0) / n * 1e3
-    # graph
-    g = torch.cuda.CUDAGraph()
-    sx = px.clone()
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        for _ in range(2):
-            model.encode_image(sx)
-    torch.cuda.current_stream().wait_stream(s)
-    with torch.cuda.graph(g):
-        out = model.encode_image(sx)
+name = os.environ.get("MODEL", "ViT-B/32")
+model, _ = mmr_amd.load(name, device=dev, weights="synthetic")
+S, E = model.input_resolution, model.cfg.embed_dim
+index = search.GalleryIndex(synth.synth_unit_rows(100_000, E, seed=1).to(dev))
+res = {"model": name, "gallery_rows": 100_000, "note": "ms per call, wall clock over 50 back-to-back calls; 1 x MI355X; seeded weights"}
+
+
+def timed(fn, n=50):
+    for _ in range(5):
+        fn()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
-        g.replay()
+        fn()
     torch.cuda.synchronize()
-    graph = (time.perf_counter() - t0) / n * 1e3
-    ok = torch.equal(out, model.encode_image(sx))
-    print(f"B={B:3d}: eager {eager:.3f} ms  graph {graph:.3f} ms  ({B/eager*1e3:.0f} / {B/graph*1e3:.0f} img/s) same={ok}", flush=True)
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for B in [int(x) for x in os.environ.get("BS", "1,10,32").split(",")]:
+    px = torch.randn(B, 3, S, S, device=dev)
+
+    def enc():
+        return model.encode_image(px, normalize=True)
+
+    def enc_search():
+        return index.search(model.encode_image(px, normalize=True), 10)
+
+    row = {}
+    for tag, fn in (("encode", enc), ("encode+top10", enc_search)):
+        eager = timed(fn)
+        ref = fn()
+        ref = [t.clone() for t in (ref if isinstance(ref, tuple) else (ref,))]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                out = fn()
+        torch.cuda.current_stream().wait_stream(side)
+        out = out if isinstance(out, tuple) else (out,)
+        replay = timed(g.replay)
+        same = all(torch.equal(a, b) for a, b in zip(out, ref))
+        row[tag] = {"eager_ms": round(eager, 4), "graph_replay_ms": round(replay, 4), "replay_equals_eager": bool(same),
+                    "images_per_s_eager": round(B / eager * 1e3, 1), "images_per_s_graph": round(B / replay * 1e3, 1)}
+    res[f"batch_{B}"] = row
+print(json.dumps(res, indent=1))
