@@ -20,6 +20,15 @@ index = search.GalleryIndex(gal)
 ref_img = model.encode_image(px, normalize=True).clone()
 ref_txt = model.encode_text(ids, normalize=True).clone()
 ref_s = [t.clone() for t in index.search(q, 10, 1.0)]
+# the other scan kernels: E = 768 bf16 (scan16_kernel) and fp32 galleries (scan_f32s_kernel: LDS-DMA ring + split images)
+extra = []
+for E, dt, nq in ((768, torch.bfloat16, 128), (512, torch.float32, 128), (768, torch.float32, 64), (128, torch.float32, 100),
+                  (256, torch.float32, 33)):
+    g2 = torch.randn(200_003, E, device=dev)
+    g2 = (g2 / g2.norm(dim=-1, keepdim=True)).to(dt)
+    q2 = g2[5:5 + nq].clone()
+    ix = search.GalleryIndex(g2)
+    extra.append((ix, q2, [t.clone() for t in ix.search(q2, 10, 1.0, return_dot64=True, return_status=True)]))
 side = torch.cuda.Stream(dev)
 big = torch.randn(8192, 8192, device=dev, dtype=torch.bfloat16)
 bad = 0
@@ -35,6 +44,9 @@ for it in range(iters):
     s = index.search(q, 10, 1.0)
     bad += int(not torch.equal(a, ref_img)) + int(not torch.equal(t, ref_txt))
     bad += int(not (torch.equal(s[0], ref_s[0]) and torch.equal(s[1], ref_s[1])))
+    for ix, q2, ref in extra:
+        got = ix.search(q2, 10, 1.0, return_dot64=True, return_status=True)
+        bad += int(not all(torch.equal(a_, b_) for a_, b_ in zip(got, ref)))     # ids, scores, fp64 dots AND the path status
 torch.cuda.synchronize()
 print(f"{iters} iterations, mismatches: {bad}")
 sys.exit(1 if bad else 0)
