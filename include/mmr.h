@@ -89,6 +89,13 @@ int mmr_l2norm_rows(void *x, mmr_dtype dtype, int64_t rows, int E, void *stream)
 int mmr_topk_merge(const int64_t *idx_parts, const double *dot_parts, int parts, int Q, int k, float scale,
                    int64_t *idx, float *score, double *dot64, void *stream);
 
+/* The same exchange with ONE message per rank: mmr_topk_pack writes packed[Q,k,2] int64 = (local id + row_offset or -1,
+ * fp64 dot bits) from mmr_cosine_topk's idx/dot64; after the all-gather of those messages ([parts,Q,k,2])
+ * mmr_topk_merge_packed ranks them.  Two launches around the collective instead of six tensor ops. */
+int mmr_topk_pack(const int32_t *idx, const double *dot64, int Q, int k, int64_t row_offset, int64_t *packed, void *stream);
+int mmr_topk_merge_packed(const int64_t *packed_parts, int parts, int Q, int k, float scale, int64_t *idx, float *score,
+                          double *dot64, void *stream);
+
 /* Multi-GPU leg for hosts without torch.distributed: one process per GPU; rank r searches its
  * gallery rows with mmr_cosine_topk(_ex), adds its row offset to the ids (int64, -1 stays -1), then ONE RCCL all-gather
  * over xGMI of the per-shard (id, fp64 dot) lists and mmr_topk_merge.  librccl is bound at run time (dlopen; MMR_RCCL_LIB

@@ -63,6 +63,10 @@ def lib():
     L.mmr_l2norm_rows.argtypes = [vp, i32, i64, i32, vp]
     L.mmr_topk_merge.restype = i32
     L.mmr_topk_merge.argtypes = [vp, vp, i32, i32, i32, f32, vp, vp, vp, vp]
+    L.mmr_topk_pack.restype = i32
+    L.mmr_topk_pack.argtypes = [vp, vp, i32, i32, i64, vp, vp]
+    L.mmr_topk_merge_packed.restype = i32
+    L.mmr_topk_merge_packed.argtypes = [vp, i32, i32, i32, f32, vp, vp, vp, vp]
     L.mmr_comm_unique_id.restype = i32
     L.mmr_comm_unique_id.argtypes = [vp]
     L.mmr_comm_init.restype = i32

@@ -1342,7 +1342,21 @@ __global__ void fill_empty_kernel(int32_t *idx, float *score, double *dot64, int
     }
 }
 
+// this rank's message for the all-gather: packed[q][j] = (global id = local id + offset, or -1; fp64 dot bits)
+__global__ void pack_kernel(const int32_t *__restrict__ idx, const double *__restrict__ dot, int64_t offset, int n,
+                            int64_t *__restrict__ packed)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const int32_t li = idx[i];
+        packed[2 * (size_t)i] = li >= 0 ? (int64_t)li + offset : -1;
+        packed[2 * (size_t)i + 1] = __double_as_longlong(dot[i]);
+    }
+}
+
 // parts*k <= 8*64 candidates with int64 global ids: one wave, candidates in registers.
+// PACKED: the lists arrive as the gathered messages themselves, [parts][Q][k][2] int64 = (id, dot bits).
+template <bool PACKED>
 __global__ __launch_bounds__(64) void merge_kernel(const int64_t *__restrict__ idx_parts,
                                                     const double *__restrict__ dot_parts, int parts, int Q, int k,
                                                     float scale, int64_t *__restrict__ idx, float *__restrict__ score,
@@ -1360,8 +1374,8 @@ __global__ __launch_bounds__(64) void merge_kernel(const int64_t *__restrict__ i
         v[j] = -INFINITY; key[j] = NONE;
         if (i < n) {
             const size_t o = ((size_t)(i / k) * Q + qi) * k + (i % k);
-            const int64_t gi = idx_parts[o];
-            const double d = dot_parts[o];
+            const int64_t gi = PACKED ? idx_parts[2 * o] : idx_parts[o];
+            const double d = PACKED ? __longlong_as_double(idx_parts[2 * o + 1]) : dot_parts[o];
             if (gi >= 0 && d == d) { v[j] = d; key[j] = gi; }
         }
     }
@@ -1798,8 +1812,34 @@ extern "C" int mmr_topk_merge(const int64_t *idx_parts, const double *dot_parts,
     if (Q == 0) return MMR_OK;
     MMR_CHECK_ARG(idx_parts && dot_parts && idx && score, "mmr_topk_merge: null pointer");
     MMR_CHECK_ARG(parts * k <= 1024, "mmr_topk_merge: parts*k=%d exceeds 1024", parts * k);
-    hipLaunchKernelGGL(merge_kernel, dim3(Q), dim3(64), 0, (hipStream_t)stream, idx_parts, dot_parts, parts, Q, k,
+    hipLaunchKernelGGL(merge_kernel<false>, dim3(Q), dim3(64), 0, (hipStream_t)stream, idx_parts, dot_parts, parts, Q, k,
                        scale, idx, score, dot64);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+extern "C" int mmr_topk_pack(const int32_t *idx, const double *dot64, int Q, int k, int64_t row_offset, int64_t *packed,
+                             void *stream)
+{
+    MMR_CHECK_ARG(Q >= 0 && k >= 1 && k <= K_MAX, "mmr_topk_pack: bad shape Q=%d k=%d", Q, k);
+    if (Q == 0) return MMR_OK;
+    MMR_CHECK_ARG(idx && dot64 && packed, "mmr_topk_pack: null pointer");
+    const int n = Q * k;
+    hipLaunchKernelGGL(pack_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, idx, dot64, row_offset, n, packed);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+extern "C" int mmr_topk_merge_packed(const int64_t *packed_parts, int parts, int Q, int k, float scale, int64_t *idx,
+                                     float *score, double *dot64, void *stream)
+{
+    MMR_CHECK_ARG(parts >= 1 && Q >= 0 && k >= 1 && k <= K_MAX, "mmr_topk_merge_packed: bad shape parts=%d Q=%d k=%d", parts, Q, k);
+    MMR_CHECK_ARG(scale > 0.f, "mmr_topk_merge_packed: scale must be > 0");
+    if (Q == 0) return MMR_OK;
+    MMR_CHECK_ARG(packed_parts && idx && score, "mmr_topk_merge_packed: null pointer");
+    MMR_CHECK_ARG(parts * k <= 1024, "mmr_topk_merge_packed: parts*k=%d exceeds 1024", parts * k);
+    hipLaunchKernelGGL(merge_kernel<true>, dim3(Q), dim3(64), 0, (hipStream_t)stream, packed_parts, (const double *)nullptr,
+                       parts, Q, k, scale, idx, score, dot64);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }

@@ -185,6 +185,20 @@ def merge_topk(idx_parts: torch.Tensor, dot_parts: torch.Tensor, scale: float = 
     return score, idx, dot64
 
 
+def merge_topk_packed(gathered: torch.Tensor, scale: float = 1.0):
+    """Merge the gathered per-shard messages [parts,Q,k,2] int64 (mmr_topk_pack layout) -> (values, indices, dot64)."""
+    gathered = gathered.contiguous()
+    parts, Q, k, _ = gathered.shape
+    dev = gathered.device
+    idx = torch.empty(Q, k, dtype=torch.int64, device=dev)
+    score = torch.empty(Q, k, dtype=torch.float32, device=dev)
+    dot64 = torch.empty(Q, k, dtype=torch.float64, device=dev)
+    L = _lib.lib()
+    _lib.check(L.mmr_topk_merge_packed(gathered.data_ptr(), parts, Q, k, float(scale), idx.data_ptr(), score.data_ptr(),
+                                       dot64.data_ptr(), _lib.stream_ptr(dev)))
+    return score, idx, dot64
+
+
 class GalleryIndex:
     """A device-resident embedding matrix [N,E] with a reusable search workspace.
 
@@ -225,6 +239,18 @@ class GalleryIndex:
             out = out + (status,)
         return out
 
+    def search_packed(self, queries2d: torch.Tensor, k: int, scale: float, row_offset: int) -> torch.Tensor:
+        """This shard's all-gather message for [Q,E] queries: [Q,k,2] int64 = (global row id or -1, fp64 dot bits),
+        written by one kernel straight from the search outputs (mmr_topk_pack)."""
+        q = queries2d.to(device=self.gallery.device, dtype=self.gallery.dtype).contiguous()
+        idx, _, dot64, _, self._ws = _local_topk(q, self.gallery, int(k), scale, self.norm_bound, True, False, self._ws,
+                                                 self.norm_bound_dev)
+        packed = torch.empty(q.shape[0], int(k), 2, dtype=torch.int64, device=q.device)
+        L = _lib.lib()
+        _lib.check(L.mmr_topk_pack(idx.data_ptr(), dot64.data_ptr(), q.shape[0], int(k), int(row_offset), packed.data_ptr(),
+                                   _lib.stream_ptr(q.device)))
+        return packed
+
     def scores(self, ref_feature: torch.Tensor, scale: float = 100.0) -> torch.Tensor:
         """``get_similarity``'s first line for this gallery (reference code/search_image.py:107)."""
         return similarity(self.gallery, ref_feature, scale)
@@ -241,9 +267,12 @@ class _PendingSearch:
         if self.work is not None:
             self.work.wait()          # nccl: the CURRENT STREAM waits for the collective, the host does not
             self.work = None
-        idx_parts = self.gathered[..., 0].contiguous()
-        dot_parts = self.gathered[..., 1].contiguous().view(torch.float64)
-        out = self.owner._merge(idx_parts, dot_parts, self.scale)       # (score, idx, dot64)
+        if self.owner._merge is None:                                    # HIP path: rank the gathered messages as they are
+            out = merge_topk_packed(self.gathered, self.scale)
+        else:
+            idx_parts = self.gathered[..., 0].contiguous()
+            dot_parts = self.gathered[..., 1].contiguous().view(torch.float64)
+            out = self.owner._merge(idx_parts, dot_parts, self.scale)   # (score, idx, dot64)
         if self.squeezed:
             out = tuple(t[0] for t in out)
         return out if return_dot64 else out[:2]
@@ -276,7 +305,7 @@ class ShardedGalleryIndex:
         self.local = local_gallery
         self._index = GalleryIndex(local_gallery, norm_bound) if local_search is None else None
         self._local_search = local_search
-        self._merge = merge or merge_topk
+        self._merge = merge if merge is not None else (None if local_search is None else merge_topk)
         n_local = torch.tensor([local_gallery.shape[0]], dtype=torch.int64, device=local_gallery.device)
         if self.use_dist:
             counts = torch.empty(self.world, dtype=torch.int64, device=local_gallery.device)
@@ -300,9 +329,13 @@ class ShardedGalleryIndex:
 
     def search_async(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0) -> _PendingSearch:
         squeezed = queries.dim() == 1
-        gidx, ldot = self.local_topk(queries, k, scale)
-        # one packed message per rank: [Q,k,2] int64 = (global id, fp64 dot bits)
-        packed = torch.stack([gidx, ldot.view(torch.int64)], dim=-1).contiguous()
+        if self._local_search is None:
+            q2, _ = _as_2d(queries)
+            packed = self._index.search_packed(q2, k, scale, self.offset)     # one kernel after the search
+        else:
+            gidx, ldot = self.local_topk(queries, k, scale)
+            # one packed message per rank: [Q,k,2] int64 = (global id, fp64 dot bits)
+            packed = torch.stack([gidx, ldot.view(torch.int64)], dim=-1).contiguous()
         if self.use_dist:
             # output = the ranks' messages concatenated along dim 0 (the layout both nccl and gloo accept)
             flat = torch.empty((self.world * packed.shape[0],) + tuple(packed.shape[1:]), dtype=packed.dtype,
