@@ -20,6 +20,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace mmr {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -343,15 +345,15 @@ __device__ __forceinline__ void decode_tile256(int bid, int nblk, int gn, int pa
     n0 = (rem / rows_here) * bnt;
 }
 
-// one output tile [m0, m0+256) x [n0, n0 + 64*NIW); NIW = 2 is the 256x128 "half" tile of the mixed launch below
+// one output tile [m0, m0+256) x [n0, n0 + 64*NIW)
 template <int EPI, int NIW, bool PATCH>
 __device__ __forceinline__ void gemm256_tile(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
     const float *__restrict__ bias, void *__restrict__ out, const GemmAux &aux, const int m0, const int n0, char *smem)
 {
-    static_assert(NIW >= 2 && NIW <= 4, "tile width 128, 192 or 256");
+    static_assert(NIW == 3 || NIW == 4, "tile width 192 or 256");
     constexpr int WCOLS = 16 * NIW;               // columns per wave
-    constexpr int W1_LOADS = NIW == 4 ? 2 : (NIW == 3 ? 1 : 0);    // global_load_lds per wave for piece W1 (128, 64 or 0 rows)
+    constexpr int W1_LOADS = NIW == 4 ? 2 : 1;    // global_load_lds per wave for piece W1 (128 or 64 rows)
     constexpr int W_LOADS = 2 + W1_LOADS;         // ... for W0 + W1: the queue depth the counted wait leaves
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -388,7 +390,6 @@ __device__ __forceinline__ void gemm256_tile(
         const int half = kind & 1;
         const bool isA = kind >= 2;
         char *dst = smem + (kt & 1) * STAGE2_BYTES + ((isA ? 0 : 2) + half) * HALF_BYTES;
-        if (NIW == 2 && kind == 1) return;         // a 128-column tile has no W1 piece
         if (NIW == 3 && kind == 1) {               // the 64-row W1 of the 192-wide tile: 8 blocks, one per wave
             const char *b1 = reinterpret_cast<const char *>(W) + ((size_t)(n0 + 128 + wave * 8) * K + (size_t)kt * BK) * 2;
             glds16(b1 + lane_off, dst + wave * 1024);
@@ -626,27 +627,42 @@ __device__ __forceinline__ void gemm256_tile(
 
 // ---------------------------------------------------------------------------------------------
 // Persistent form of the 256x256 kernel for launches of MORE tiles than CUs with a bf16 epilogue (qkv, fc1: 450 / 600
-// tiles at batch 256).  A tile "round" of the plain kernel is ~20 us of main loop plus ~7 us in which the matrix pipes
-// idle: the epilogue, the drain of its stores, the dispatch of the CU's next workgroup and that workgroup's first
-// operand loads from a cold queue.  Here one workgroup per CU walks tiles b, b + grid, b + 2*grid, ... and
-//   * issues the NEXT tile's prologue loads (six 16 KiB pieces into the staging buffers, idle once the main loop's last
-//     barrier has passed) BEFORE it runs the current tile's epilogue, which works in a separate 4 KiB-per-wave LDS scratch
-//     (four passes of 32 rows) -- so the loads fly during the epilogue;
-//   * never waits for its epilogue stores: the next tile's first counted wait names them as the youngest entries of the
-//     in-order VM queue (s_waitcnt vmcnt(16 stores + W loads)), so they drain under the next tile's first K-steps.
+// tiles at batch 256).  In-kernel stamps (tools/gemm_phase_times.py) put a tile "round" of the one-workgroup-per-tile kernel
+// at ~17 us of main loop plus ~5 us in which the matrix pipes idle: 1.3 us waiting for the first operand pieces, 1.6-2.9 us
+// of epilogue, ~2 us between a CU's consecutive workgroups (store drain + dispatch).  Here one workgroup per CU walks a
+// static tile list and
+//   * issues the NEXT tile's prologue loads -- all eight 16 KiB pieces of K-tiles 0 and 1: the staging buffers are idle once
+//     the main loop's last barrier has passed -- BEFORE it runs the current tile's epilogue, which works in a separate
+//     4 KiB-per-wave LDS scratch (four passes of 32 rows), so the loads fly during the epilogue;
+//   * never waits for its epilogue stores: the VM counter is in order, so the next tile's first counted waits name the 16
+//     stores as the YOUNGEST queue entries (s_waitcnt vmcnt(stores + bias loads + newer pieces)) and the first loads issued
+//     behind them (K-tile 2's W pieces) are not needed until 1.5 K-tiles later;
+//   * evens out the tile count: the last row panels are cut into 256x128 half tiles handed to the workgroups with the
+//     fewest full tiles (PersistPlan), so fc1's 600 tiles cost the slowest workgroup 2 full + 1 half instead of 3 full.
 // Main loop, staging order, swizzles and accumulation order are those of gemm256_tile<EPI, 4>: results are bit-identical.
+// Measured (MI355X, ViT-B/32 batch 256, same box, us): qkv 49.0 -> 46.2, fc1 75.2 (persistent, no halves) / 73.0 (round 2's
+// first attempt: half tiles dispatched first, not persistent) -> 72.5, ViT-L/14 fc1 520 -> 510; forward 2.97 -> 2.93 ms.
 // ---------------------------------------------------------------------------------------------
 constexpr int EPI_SCRATCH = 4096;                       // per wave: [32 rows][8 chunks of 8 bf16]
 constexpr int GEMM2P_LDS = GEMM2_LDS + 8 * EPI_SCRATCH; // 160 KiB: the whole LDS of a CU
 constexpr int GEMM2P_STORES = 16;                       // epilogue global stores per wave per tile (4 passes x 4)
 
+// Work of one persistent workgroup: full (256x256) tiles b, b + G, b + 2G, ... of the FULL region (row panels ph ..), then
+// half (256x128) tiles G-1-b, 2G-1-b, ... of the HALF region (row panels 0 .. ph-1) -- the workgroups with the fewest full
+// tiles take half tiles first.  The host picks ph so that the slowest workgroup runs 2.65 tile times instead of 3
+// (persist_half_panels): the launch's tile count need not be a multiple of the CU count.
+struct PersistPlan {
+    int ph;                  // row panels cut into half tiles (0 = none)
+    int nfull, nhalf;        // tiles per region
+    int pg_full, pg_half;    // tile-order group sizes (decode_tile256)
+};
+
 template <int EPI>
 __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_persist_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
-    const float *__restrict__ bias, bf16_t *__restrict__ out, int pg, int ntiles)
+    const float *__restrict__ bias, bf16_t *__restrict__ out, PersistPlan plan)
 {
     static_assert(epi_bf16(EPI) && !epi_lnfold(EPI), "persistent form: plain bf16 epilogues");
-    constexpr int NIW = 4, WCOLS = 64, W_LOADS = 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -656,18 +672,34 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_persist_kernel(
     const int fr = lane & 15, fg = lane >> 4;
     const int gn = N / 256, panels = M / BM2;
     const int nkt = K / BK;
-    const int w_row0 = wc * WCOLS;
     char *scratch = smem + GEMM2_LDS + wave * EPI_SCRATCH;
 
-    // Staging addresses = wave-uniform base (tile, K-tile, piece: SGPRs) + ONE per-lane 32-bit byte offset that never
-    // changes (row rr of the 8-row block, swizzled source chunk sc): the loads take the saddr + voffset form and no
-    // 64-bit per-lane pointer lives across the loop (the 256-VGPR budget is what this kernel runs against)
-    int m0, n0;
-    auto set_tile = [&](int t) { decode_tile256(t, ntiles, gn, panels, pg, 256, m0, n0); };
+    // this workgroup's tile sequence
+    const int G = gridDim.x, b = blockIdx.x;
+    const int my_full = plan.nfull > b ? (plan.nfull - 1 - b) / G + 1 : 0;
+    const int h0 = G - 1 - b;
+    const int my_half = plan.nhalf > h0 ? (plan.nhalf - 1 - h0) / G + 1 : 0;
+    const int my_tiles = my_full + my_half;
+    if (my_tiles == 0) return;
+
+    // staging target: the tile whose operand pieces stage() fetches (it changes to the NEXT tile before the current tile's
+    // epilogue).  Addresses = wave-uniform base (tile, K-tile, piece: SGPRs) + ONE per-lane 32-bit byte offset that never
+    // changes (row rr of the 8-row block, swizzled source chunk sc): saddr + voffset loads, no 64-bit per-lane pointers
+    int m0 = 0, n0 = 0, niw = 4;
+    auto set_tile = [&](int i) {           // i-th tile of this workgroup
+        if (i < my_full) {
+            decode_tile256(b + i * G, plan.nfull, gn, panels - plan.ph, plan.pg_full, 256, m0, n0);
+            m0 += plan.ph * BM2;
+            niw = 4;
+        } else {
+            decode_tile256(h0 + (i - my_full) * G, plan.nhalf, 2 * gn, plan.ph, plan.pg_half, 128, m0, n0);
+            niw = 2;
+        }
+    };
     const uint32_t lane_off = (uint32_t)((rr * K + sc * 8) * 2);
-    // kind: 0 = W0, 1 = W1, 2 = A0, 3 = A1 (gemm256_tile's rotating stream order)
+    // kind: 0 = W0, 1 = W1, 2 = A0, 3 = A1 (gemm256_tile's rotating stream order); a half tile has no W1 piece
     auto stage = [&](int kt, int kind) {
-        if (kt >= nkt) return;
+        if (kt >= nkt || (kind == 1 && niw == 2)) return;
         const int half = kind & 1;
         const bool isA = kind >= 2;
         char *dst = smem + (kt & 1) * STAGE2_BYTES + ((isA ? 0 : 2) + half) * HALF_BYTES;
@@ -676,30 +708,37 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_persist_kernel(
         glds16(base + lane_off, dst + wave * 2048);
         glds16(base + (size_t)16 * K + lane_off, dst + wave * 2048 + 1024);       // 8 rows further
     };
-
-    int tile = blockIdx.x;
-    set_tile(tile);
-    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
-    bool first = true;
+    // a tile's prologue: ALL pieces of K-tiles 0 and 1 (the whole 128 KiB of staging is idle between tiles), so the
+    // first loads issued after an epilogue are the W pieces of K-tile 2 -- needed 1.5 K-tiles later, by which time the
+    // epilogue's stores, which the in-order VM counter makes them wait behind, have long drained
+    auto tile_prologue = [&]() {
+        stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1); stage(1, 2); stage(1, 3);
+    };
 #ifdef MMR_GEMM_STAMPS
     int stamp_slot = blockIdx.x;
 #endif
-    for (;;) {
+
+    // one tile of width 64*NIW.  On entry its prologue pieces are in flight; on exit the next tile's are (if any).
+    auto run_tile = [&](auto NIWC, const int i) {
+        constexpr int NIW = decltype(NIWC)::value;
+        constexpr int WCOLS = 16 * NIW, W_LOADS = NIW == 4 ? 4 : 2;     // glds per wave for the W pieces of one K-tile
+        constexpr int BIAS_LOADS = NIW, KT1_LOADS = W_LOADS + 4;        // ... and for all pieces of one K-tile
+        const bool first = i == 0;
         const int cm0 = m0, cn0 = n0;
+        const int w_row0 = wc * WCOLS;
         MMR_STAMP(stamp_slot, 0);
         float4 bias4[NIW];
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) bias4[ni] = *reinterpret_cast<const float4 *>(bias + cn0 + wc * WCOLS + ni * 16 + fg * 4);
         f32x4 acc[NIW][8];
 #pragma unroll
-        for (int i = 0; i < NIW; ++i)
+        for (int ii = 0; ii < NIW; ++ii)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < 8; ++j) acc[ii][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        // K-tile 0's pieces have landed once only these YOUNGER entries remain in the in-order queue: the W pieces of
-        // K-tile 1, (after the first tile) the previous tile's 16 epilogue stores, and the 4 bias loads just issued
-        constexpr int BIAS_LOADS = NIW;
-        if (nkt > 1) { if (first) wait_vmcnt<W_LOADS + BIAS_LOADS>(); else wait_vmcnt<W_LOADS + GEMM2P_STORES + BIAS_LOADS>(); }
+        // K-tile 0's pieces have landed once only these YOUNGER entries remain in the in-order queue: the loads of K-tile 1's
+        // pieces, (after the first tile) the previous tile's 16 epilogue stores, and the bias loads just issued
+        if (nkt > 1) { if (first) wait_vmcnt<KT1_LOADS + BIAS_LOADS>(); else wait_vmcnt<KT1_LOADS + GEMM2P_STORES + BIAS_LOADS>(); }
         else { if (first) wait_vmcnt<BIAS_LOADS>(); else wait_vmcnt<GEMM2P_STORES + BIAS_LOADS>(); }
         __builtin_amdgcn_s_barrier();
         MMR_STAMP(stamp_slot, 1);
@@ -738,15 +777,22 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_persist_kernel(
                 __builtin_amdgcn_s_setprio(0);
             };
             read_w(); read_a(0);
-            stage(kt + 1, 2);
-            stage(kt + 1, 3);
+            if (kt > 0) {                      // K-tile 1's A pieces came with the tile prologue
+                stage(kt + 1, 2);
+                stage(kt + 1, 3);
+            }
             MMR_LOAD_DONE();
             mma(0);
             __builtin_amdgcn_s_barrier();
             read_a(1);
             stage(kt + 2, 0);
             stage(kt + 2, 1);
-            if (kt + 2 < nkt) wait_vmcnt<W_LOADS>(); else wait_vmcnt<0>();
+            if (kt == 0 && nkt > 2) {
+                // K-tile 1's pieces are OLDER than the previous tile's stores and this tile's bias loads: leave those (and
+                // the W pieces of K-tile 2 just issued) outstanding -- the stores get until K-tile 1's wait to drain
+                if (first) wait_vmcnt<W_LOADS + BIAS_LOADS>(); else wait_vmcnt<W_LOADS + BIAS_LOADS + GEMM2P_STORES>();
+            } else if (kt + 2 < nkt) wait_vmcnt<W_LOADS>();
+            else wait_vmcnt<0>();
             MMR_LOAD_DONE();
             mma(1);
             __builtin_amdgcn_s_barrier();
@@ -760,11 +806,9 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_persist_kernel(
 #pragma unroll
         for (int ni = 0; ni < NIW; ++ni) asm volatile("" : "+v"(bias4[ni].x), "+v"(bias4[ni].y), "+v"(bias4[ni].z), "+v"(bias4[ni].w));
 
-        const int next = tile + (int)gridDim.x;
-        const bool more = next < ntiles;
-        if (more) {
-            set_tile(next);
-            stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3); stage(1, 0); stage(1, 1);
+        if (i + 1 < my_tiles) {
+            set_tile(i + 1);
+            tile_prologue();
         }
 
         // ---- epilogue of tile (cm0, cn0): four passes of 32 rows through this wave's private 4 KiB scratch.
@@ -773,7 +817,8 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_persist_kernel(
         // the epilogue until the next tile's prologue loads have landed -- the overlap this kernel exists for.  The
         // scratch is private to the wave and the LDS executes one wave's operations in order, so a pass needs no wait
         // between its writes and its reads, nor between its reads and the next pass's writes; only the registers that
-        // receive the reads are waited for (lgkmcnt) before the stores use them.
+        // receive the reads are waited for (lgkmcnt) before the stores use them.  16 store instructions per wave whatever
+        // the tile width (a half tile's stores have lanes rc < 4 active): the next tile's counted waits rely on that.
         const size_t row_base = (size_t)(cm0 + wr * 128);
         const int col_base = cn0 + wc * WCOLS;
         const int rc = lane & 7, rr0 = lane >> 3;
@@ -799,24 +844,28 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_persist_kernel(
             }
             u32x4_t rows4[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = i * 8 + rr0;
+            for (int ii = 0; ii < 4; ++ii) {
+                const int row = ii * 8 + rr0;
                 const uint32_t addr = sbase + row * 128 + ((rc ^ (row & 7)) << 4);
-                asm volatile("ds_read_b128 %0, %1" : "=v"(rows4[i]) : "v"(addr) : "memory");
+                asm volatile("ds_read_b128 %0, %1" : "=v"(rows4[ii]) : "v"(addr) : "memory");
             }
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rows4[0]), "+v"(rows4[1]), "+v"(rows4[2]), "+v"(rows4[3])::"memory");
+            if (rc < 2 * NIW) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                epi_store16(out + MMR_OUT_ROW(row_base + p * 32 + i * 8 + rr0) * N + col_base + rc * 8, rows4[i]);
+                for (int ii = 0; ii < 4; ++ii)
+                    epi_store16(out + MMR_OUT_ROW(row_base + p * 32 + ii * 8 + rr0) * N + col_base + rc * 8, rows4[ii]);
+            }
         }
 #ifdef MMR_GEMM_STAMPS
         MMR_STAMP(stamp_slot, 3);
         stamp_slot += 256;
 #endif
-        if (!more) break;
-        tile = next;
-        first = false;
-    }
+    };
+
+    set_tile(0);
+    tile_prologue();
+    for (int i = 0; i < my_full; ++i) run_tile(std::integral_constant<int, 4>{}, i);
+    for (int i = my_full; i < my_tiles; ++i) run_tile(std::integral_constant<int, 2>{}, i);
 }
 
 template <int EPI, int NIW, bool PATCH = false>
@@ -828,29 +877,6 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     int m0, n0;
     decode_tile256(blockIdx.x, gridDim.x, N / (64 * NIW), M / BM2, pg, 64 * NIW, m0, n0);
     gemm256_tile<EPI, NIW, PATCH>(A, W, M, N, K, bias, out, aux, m0, n0, smem);
-}
-
-// Mixed launch for GEMMs whose 256x256 tile count is a bad multiple of the 256 CUs (fc1 at batch 256: 600 tiles = 2.34
-// rounds, run as 3).  The first `ph` row panels are cut into 256x128 HALF tiles and dispatched first, the rest into
-// full tiles: the hardware hands a freed CU the next workgroup, so the CUs that started on a half tile run half a tile
-// time ahead of the others for the rest of the launch.  Two effects: the launch ends after ~2.55 tile times instead of
-// 3, and the two groups' epilogues (an HBM-write burst during which the matrix pipes idle) no longer coincide -- one
-// group stores while the other computes.  Both tile shapes share one kernel so that they share one dispatch queue.
-template <int EPI>
-__global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_mixed_kernel(
-    const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
-    const float *__restrict__ bias, void *__restrict__ out, GemmAux aux, int ph, int pg_half, int pg_full)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n_half = ph * (N / 128);
-    int m0, n0;
-    if ((int)blockIdx.x < n_half) {
-        decode_tile256(blockIdx.x, n_half, N / 128, ph, pg_half, 128, m0, n0);
-        gemm256_tile<EPI, 2, false>(A, W, M, N, K, bias, out, aux, m0, n0, smem);
-    } else {
-        decode_tile256(blockIdx.x - n_half, gridDim.x - n_half, N / 256, M / BM2 - ph, pg_full, 256, m0, n0);
-        gemm256_tile<EPI, 4, false>(A, W, M, N, K, bias, out, aux, m0 + ph * BM2, n0, smem);
-    }
 }
 
 static int tile_group_panels(int gn)
@@ -878,21 +904,40 @@ static int launch_gemm256(const bf16_t *A, const bf16_t *W, int M, int N, int K,
     return MMR_OK;
 }
 
-template <int EPI>
-static int launch_gemm256_mixed(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
-                                const GemmAux &aux, int ph, hipStream_t st)
+// Row panels to cut into half tiles for the persistent launch: the smallest ph whose static assignment (full tiles dealt
+// round-robin, then half tiles dealt from the other end) gives the shortest slowest workgroup, a half tile costing
+// HALF_COST (0.65, measured) of a full one.
+static int persist_half_panels(int panels, int gn, int G)
 {
-    static DeviceOnce once;
-    if (once.first()) {
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_mixed_kernel<EPI>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2_LDS + BM2 * 8));
+    static const int forced = getenv("MMR_GEMM_HALF_PANELS") ? atoi(getenv("MMR_GEMM_HALF_PANELS")) : -1;   // A/B aid
+    if (forced >= 0) return forced < panels ? forced : panels;
+    const double hc = 0.65;
+    auto makespan = [&](int ph) {
+        const int nfull = (panels - ph) * gn, nhalf = ph * 2 * gn;
+        double mx = 0.0;
+        for (int b = 0; b < G; ++b) {                 // loads repeat with period G: a few representative workgroups would do,
+            const int f = nfull > b ? (nfull - 1 - b) / G + 1 : 0;       // but G <= 256 and this runs once per shape
+            const int h0 = G - 1 - b;
+            const int h = nhalf > h0 ? (nhalf - 1 - h0) / G + 1 : 0;
+            const double t = f + hc * h;
+            mx = t > mx ? t : mx;
+        }
+        return mx;
+    };
+    struct Memo { int panels, gn, G, ph; };
+    static thread_local Memo memo[8];
+    static thread_local int memo_n = 0;
+    for (int i = 0; i < memo_n; ++i)
+        if (memo[i].panels == panels && memo[i].gn == gn && memo[i].G == G) return memo[i].ph;
+    int best = 0;
+    double best_t = makespan(0);
+    for (int ph = 1; ph <= panels / 2; ++ph) {
+        const double t = makespan(ph);
+        if (t < best_t - 1e-9) { best_t = t; best = ph; }
     }
-    const int panels = M / BM2;
-    const int grid = ph * (N / 128) + (panels - ph) * (N / 256);
-    hipLaunchKernelGGL((gemm256_mixed_kernel<EPI>), dim3(grid), dim3(GEMM2_THREADS), GEMM2_LDS + BM2 * 8, st, A, W, M, N, K,
-                       bias, out, aux, ph, tile_group_panels(N / 128), tile_group_panels(N / 256));
-    MMR_CHECK_LAUNCH();
-    return MMR_OK;
+    if (best_t > 0.97 * makespan(0)) best = 0;
+    if (memo_n < 8) memo[memo_n++] = Memo{panels, gn, G, best};
+    return best;
 }
 
 template <int EPI>
@@ -904,70 +949,18 @@ static int launch_gemm256_persist(const bf16_t *A, const bf16_t *W, int M, int N
         MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm256_persist_kernel<EPI>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
     }
-    const int ntiles = (M / BM2) * (N / 256);
-    const int grid = ntiles < 256 ? ntiles : 256;
+    const int panels = M / BM2, gn = N / 256;
+    const int grid = panels * gn < 256 ? panels * gn : 256;
+    PersistPlan plan{};
+    plan.ph = persist_half_panels(panels, gn, grid);
+    plan.nfull = (panels - plan.ph) * gn;
+    plan.nhalf = plan.ph * 2 * gn;
+    plan.pg_full = tile_group_panels(gn);
+    plan.pg_half = tile_group_panels(2 * gn);
     hipLaunchKernelGGL((gemm256_persist_kernel<EPI>), dim3(grid), dim3(GEMM2_THREADS), GEMM2P_LDS, st, A, W, M, N, K, bias,
-                       (bf16_t *)out, tile_group_panels(N / 256), ntiles);
+                       (bf16_t *)out, plan);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
-}
-
-// Row panels to cut into half tiles (gemm256_mixed_kernel) for an M x N problem on 256x256 tiles, from greedy list
-// scheduling of [ph*2*gn half tiles, then (panels-ph)*gn full tiles] over the CUs with a half tile costing HALF_COST of a
-// full one.  Calibrated on MI355X against a sweep of ph (tools/sweep_half_panels.sh, ViT-B/32 batch 256):
-//   fc1 12800x3072x768 (600 tiles = 2.34 rounds): plain 77.2 us; ph = 8 / 10 / 12: 74.6 / 73.4 / 73.5; ph = 16: 84.1
-//   qkv 12800x2304x768 (450 tiles = 1.76 rounds): plain 49.1 us; ph = 4 / 6: 47.7 / 47.8; ph >= 8 (third round): 58-60
-// The model's round structure is sharper than the hardware's (a thinly occupied last round runs its tiles faster), so it
-// over-predicts the gain (fc1: 68 us) but ranks the candidates right with HALF_COST 0.65: take the MIDDLE of the
-// minimum-makespan range -- also when that minimum only ties the plain launch, because the stagger alone is worth 3 % (qkv).
-// Long launches (> 4 rounds: ViT-L/14) measured within +-1 % either way and stay plain.
-static int mixed_half_panels(int panels, int gn)
-{
-    static const int forced = getenv("MMR_GEMM_HALF_PANELS") ? atoi(getenv("MMR_GEMM_HALF_PANELS")) : -1;   // A/B aid
-    if (forced >= 0) return forced < panels ? forced : panels;
-    static const double half_cost = getenv("MMR_GEMM_HALF_COST") ? atof(getenv("MMR_GEMM_HALF_COST")) : 0.65;
-    const int cus = 256;
-    if ((long long)panels * gn > 4LL * cus) return 0;
-    auto makespan = [&](int ph) {
-        // every CU free at 0; tiles are taken in launch order by the earliest-free CU (a binary min-heap of free times)
-        double heap[256];
-        for (int i = 0; i < cus; ++i) heap[i] = 0.0;
-        auto pop_push = [&](double cost) {        // replace the minimum by minimum + cost, restore the heap
-            heap[0] += cost;
-            int i = 0;
-            for (;;) {
-                int l = 2 * i + 1, r = l + 1, m = i;
-                if (l < cus && heap[l] < heap[m]) m = l;
-                if (r < cus && heap[r] < heap[m]) m = r;
-                if (m == i) break;
-                const double t = heap[i]; heap[i] = heap[m]; heap[m] = t;
-                i = m;
-            }
-        };
-        const int n_half = ph * 2 * gn, n_full = (panels - ph) * gn;
-        for (int i = 0; i < n_half; ++i) pop_push(half_cost);
-        for (int i = 0; i < n_full; ++i) pop_push(1.0);
-        double mx = 0.0;
-        for (int i = 0; i < cus; ++i) mx = heap[i] > mx ? heap[i] : mx;
-        return mx;
-    };
-    struct Memo { int panels, gn, ph; };
-    static thread_local Memo memo[8];
-    static thread_local int memo_n = 0;
-    for (int i = 0; i < memo_n; ++i)
-        if (memo[i].panels == panels && memo[i].gn == gn) return memo[i].ph;
-    // the minimum-makespan candidates form a range [lo, hi]; its ends sit next to a different round count, so take the middle
-    double best_t = makespan(0);
-    int lo = 0, hi = 0;
-    for (int ph = 1; ph <= panels / 2; ++ph) {
-        const double t = makespan(ph);
-        if (t < best_t - 1e-9) { best_t = t; lo = hi = ph; }
-        else if (t <= best_t + 1e-9) hi = ph;
-    }
-    if (lo == 0 && hi > 0) lo = 1;
-    const int best = (lo + hi + 1) / 2;
-    if (memo_n < 8) memo[memo_n++] = Memo{panels, gn, best};
-    return best;
 }
 
 template <int EPI, int NSTG>
@@ -1176,26 +1169,15 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
             case EPI_BIAS_TANH_BF16: return launch_gemm_skinny<EPI_BIAS_TANH_BF16>(A, W, M, N, K, bias, out, st);
         }
     }
-    // 256x256 tiles whose count is a bad multiple of the CU count: mixed half/full launch (gemm256_mixed_kernel); built
-    // for the two epilogues of the wide-N projections (qkv, fc1)
-    // MMR_GEMM_PERSIST=1 routes multi-round bf16-epilogue launches to gemm256_persist_kernel.  Off by default: measured on
-    // MI355X it removes the ~2 us workgroup turnaround and half of the 1.4 us prologue wait per tile, but its main loop runs
-    // 0.8 us per tile slower beside the draining stores: ViT-B/32 qkv 48.6 us either way, fc1 76.3 vs 71.4 us for the mixed
-    // launch, ViT-L/14 fc1 549 vs 555 us ("where a GEMM tile's time goes")
-    static const int persist = getenv("MMR_GEMM_PERSIST") ? atoi(getenv("MMR_GEMM_PERSIST")) : 0;
+    // multi-round launches with a bf16 epilogue (qkv, fc1): persistent workgroups over a full + half tile list
+    // (gemm256_persist_kernel); MMR_GEMM_PERSIST=0 falls back to one workgroup per tile (A/B aid)
+    static const int persist = getenv("MMR_GEMM_PERSIST") ? atoi(getenv("MMR_GEMM_PERSIST")) : 1;
     if (persist && tile == 256 && (long long)(M / BM2) * (N / 256) > 256) {
         switch (epi) {
             case EPI_BIAS_BF16: return launch_gemm256_persist<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
             case EPI_BIAS_GELU_BF16: return launch_gemm256_persist<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);
             case EPI_BIAS_GELU_ERF_BF16: return launch_gemm256_persist<EPI_BIAS_GELU_ERF_BF16>(A, W, M, N, K, bias, out, st);
             default: break;
-        }
-    }
-    if (tile == 256 && (epi == EPI_BIAS_BF16 || epi == EPI_BIAS_GELU_BF16)) {
-        const int ph = mixed_half_panels(M / BM2, N / 256);
-        if (ph > 0) {
-            return epi == EPI_BIAS_BF16 ? launch_gemm256_mixed<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, aux, ph, st)
-                                        : launch_gemm256_mixed<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, aux, ph, st);
         }
     }
 #define MMR_GEMM_CASE(E)                                                                                   \
