@@ -29,7 +29,7 @@ fetch = load(sys.argv[1], "FETCH_SIZE")
 write = load(sys.argv[2], "WRITE_SIZE")
 rows = {}
 for name in sorted(set(fetch) | set(write)):
-    if not any(k in name for k in ("scan_kernel", "gemm_bf16_kernel", "gemm256_bf16_kernel", "select_kernel",
+    if not any(k in name for k in ("scan_kernel", "gemm", "select_kernel",
                                    "rescore_kernel", "rank_kernel", "attention_kernel", "layernorm_kernel",
                                    "im2col", "embed_")):
         continue

@@ -33,8 +33,9 @@ echo "small batch done"
 ./tools/pmc_gemm_l2.sh > $O/${R}_gemm_l2_hit_miss.txt 2>&1
 cp $O/l2_fetch_probe.txt $O/${R}_l2_fetch_probe.txt
 if [ -f tools/libmmr_hip_stamps.so ]; then
-  MMR_LIB=$PWD/tools/libmmr_hip_stamps.so MMR_GEMM_HALF_PANELS=0 python tools/gemm_phase_times.py > $O/${R}_gemm_phase_times.txt 2>&1
-  echo "=== default launch policy (mixed half/full tiles where chosen)" >> $O/${R}_gemm_phase_times.txt
+  echo "=== persistent workgroups, full 256x256 tiles only (MMR_GEMM_HALF_PANELS=0)" > $O/${R}_gemm_phase_times.txt
+  MMR_LIB=$PWD/tools/libmmr_hip_stamps.so MMR_GEMM_HALF_PANELS=0 python tools/gemm_phase_times.py >> $O/${R}_gemm_phase_times.txt 2>&1
+  echo "=== default launch policy (persistent workgroups over a full + half tile list where chosen)" >> $O/${R}_gemm_phase_times.txt
   MMR_LIB=$PWD/tools/libmmr_hip_stamps.so python tools/gemm_phase_times.py >> $O/${R}_gemm_phase_times.txt 2>&1
 fi
 (for s in "fp32:tools/time_search_fp32.py" ; do python ${s#*:}; done; E=768 QS=1,32,128,256 python tools/time_search.py; QS=1,32,64,128,256,1024 python tools/time_search.py) > $O/${R}_search_timings.txt 2>&1
