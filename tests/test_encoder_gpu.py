@@ -51,9 +51,12 @@ def _check_cos(got, want, what, fold=False):
                                    (12800, 1024, 128),      # 256x256 tiles
                                    (33024, 256, 64),        # 129 tiles: workgroup count not a multiple of the 8 XCDs
                                    (11008, 768, 64),        # 43 row panels x 4: ragged last tile-order group
-                                   (35840, 512, 128),       # 280 tiles, 2 per panel: more than one round (mixed half/full launch for the bf16 epilogues)
-                                   (12800, 3072, 768), (12800, 2304, 768),  # fc1 / qkv at batch 256: 600 / 450 tiles -> mixed half/full launch
-                                   (9216, 1024, 64),        # 36 panels x 4: mixed launch with a ragged half-tile group
+                                   (35840, 512, 128),       # 280 tiles, 2 per panel: more than one round (persistent full + half tile list for the bf16 epilogues)
+                                   (12800, 3072, 768), (12800, 2304, 768),  # fc1 / qkv at batch 256: 600 / 450 tiles -> persistent launch
+                                   (9216, 1024, 64),        # 36 panels x 4 = 144 tiles of 256x256
+                                   (19712, 512, 192),       # text tower out-proj at 256 prompts: 77 panels x 2
+                                   (12928, 768, 128),       # rows a multiple of 128 but not of 256: 128x128 tiles
+                                   (6400, 768, 64),         # batch 128: 25 panels x 4 of 256x192
                                    (2304, 384, 128), (3072, 768, 3072),     # 128x128 tiles (M > 2048, too few 256-row tiles)
                                    (2048, 128, 64), (128, 3072, 768)])      # 128x32 tiles at both ends of their range
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6])
@@ -97,6 +100,30 @@ def test_gemm_epilogues(L, device, M, N, K, epi):
         bound = torch.full_like(ref, 3e-5 * scale)
     excess = ((got - ref).abs() / bound).max().item()
     assert excess <= 1.0, f"gemm epi={epi} {M}x{N}x{K}: error is {excess:.2f}x the per-element bound"
+
+
+@pytest.mark.parametrize("M,N,K", [(12928, 768, 128), (19712, 512, 64), (6400, 768, 64), (12800, 768, 64)])
+@pytest.mark.parametrize("epi", [0, 2])
+def test_gemm_stays_inside_its_operands(L, device, M, N, K, epi):
+    """Whatever tile shape the launcher picks, nothing past row M of A may reach the result (A is followed by NaN rows) and
+    nothing may be stored past row M of the output (followed by canary rows)."""
+    g = torch.Generator().manual_seed(M + epi)
+    A = torch.full((M + 256, K), float("nan"), dtype=torch.bfloat16)
+    A[:M] = (torch.randn(M, K, generator=g) * 0.5).bfloat16()
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    bias = torch.randn(N, generator=g) * 0.1
+    ref = A[:M].float() @ W.float().t() + bias
+    Ad, Wd, bd = A.to(device), W.to(device), bias.to(device)
+    dt = torch.bfloat16 if epi == 0 else torch.float32
+    out = torch.full((M + 256, N), 7.0, dtype=dt, device=device)
+    if epi == 2:
+        out[:M] = 0.0
+    L.check(L.lib().mmr_debug_gemm(epi, Ad.data_ptr(), Wd.data_ptr(), M, N, K, bd.data_ptr(), out.data_ptr(), L.stream_ptr(device)))
+    got = out.float().cpu()
+    assert torch.equal(got[M:], torch.full((256, N), 7.0)), "stores past the last output row"
+    scale = max(1.0, ref.abs().max().item())
+    bound = 2.0 ** -8 * ref.abs() + 2e-5 * scale if epi == 0 else torch.full_like(ref, 3e-5 * scale)
+    assert ((got[:M] - ref).abs() / bound).max().item() <= 1.0
 
 
 def test_gemm_rejects_bad_shapes(L, device):
