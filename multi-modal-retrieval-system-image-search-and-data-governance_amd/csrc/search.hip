@@ -780,6 +780,9 @@ __device__ __forceinline__ double quad_dot(const QuadQuery<T, PER> &q, const Qua
 // ---------------------------------------------------------------------------------------------
 // selection: extract the best (value, key) pairs in (-value, +key) order
 // ---------------------------------------------------------------------------------------------
+#ifndef MMR_SEL_THRESH
+#define MMR_SEL_THRESH 1          // -DMMR_SEL_THRESH=0: serial extraction everywhere (A/B build)
+#endif
 constexpr int32_t KEY_NONE = 0x7fffffff;
 constexpr int SEL_R = 16;                       // candidates per lane in the register path
 constexpr int SEL_FAST_MAX = SEL_R * FIN_THREADS;  // 4096
@@ -902,15 +905,139 @@ __device__ __forceinline__ void wave_select_single(int n, int rounds, F get, V *
 #pragma unroll
         for (int j = 0; j < R; ++j) {
             const int i = tid + j * 64;
-            V x = (V)-INFINITY;
-            int32_t kx = KEY_NONE;
-            if (i < n) {
-                V tv; int32_t tk;
-                if (get(i, tv, tk) && tv == tv) { x = tv; kx = tk; }
-            }
-            v[j] = x; key[j] = kx;
+            V tv; int32_t tk;
+            const bool ok = get(min(i, n - 1), tv, tk) && i < n && tv == tv;     // see wg_select: loads never sit behind a branch
+            v[j] = ok ? tv : (V)-INFINITY; key[j] = ok ? tk : KEY_NONE;
         }
         wave_rounds<V, R>(v, key, rounds, out_v, out_k, tid);
+    }
+    __syncthreads();
+}
+
+// Order-preserving unsigned image of a candidate value (the high part of Key64 / Key96)
+template <typename V> struct OrdOf;
+template <> struct OrdOf<float> {
+    using H = uint32_t;
+    static constexpr int BITS = 32;
+    __device__ __forceinline__ static H ord(float v) { return ord_f32(v); }
+    __device__ __forceinline__ static H lane_value(H v, int l) { return (H)__builtin_amdgcn_readlane((int)v, l); }
+    // lanes with v >= c as a wave mask (v_cmp straight into an SGPR pair; __ballot(v >= c) compiles to a select + re-compare)
+    __device__ __forceinline__ static uint64_t lanes_ge(H v, H c) { return __builtin_amdgcn_uicmp(v, c, 35 /* ICMP_UGE */); }
+};
+template <> struct OrdOf<double> {
+    using H = uint64_t;
+    static constexpr int BITS = 64;
+    __device__ __forceinline__ static H ord(double v) { return ord_f64(v); }
+    __device__ __forceinline__ static H lane_value(H v, int l) {
+        return ((H)(uint32_t)__builtin_amdgcn_readlane((int)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)v, l);
+    }
+    __device__ __forceinline__ static uint64_t lanes_ge(H v, H c) { return __builtin_amdgcn_uicmpl(v, c, 35 /* ICMP_UGE */); }
+};
+
+// The same selection as wave_select_single (one wave holds all n <= 64*R candidates; same results, slot for slot) without
+// its `rounds` serial max-extractions (each a 64-lane reduction of 64/96-bit keys):
+//   1. pivot: every lane takes the largest value it holds; the rounds-th largest of those 64 lane maxima (found by
+//      counting, v_readlane broadcasts) is a lower bound P of the rounds-th largest candidate overall;
+//   2. the candidates >= P -- at least `rounds`, for scattered data a few more -- are compacted into an LDS list;
+//   3. every list entry computes its rank by counting the entries that sort before it and the first `rounds` ranks are
+//      written out.  Sort key = (ord(value), ~key) as in Key64 / Key96 (keys are unique).
+// More than 64 candidates >= P (the large values crowd into few lanes, or fewer than `rounds` lanes hold anything): a
+// bitwise binary search finds the exact rounds-th largest key instead (v_cmp + s_bcnt1 per register and bit; as slow as
+// the serial extraction, but rare).  In-kernel stamps, 17 rounds over 992 candidates: serial extraction ~9 us, binary
+// search 6.9 + 2.5 us, pivot ~2.5 us.  Needs rounds <= 64.
+template <typename V, int R, typename F>
+__device__ __forceinline__ void wave_select_thresh(int n, int rounds, F get, V *out_v, int32_t *out_k) {
+    using O = OrdOf<V>;
+    using H = typename O::H;
+    __shared__ V cv[64];
+    __shared__ int32_t ck[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        H hi[R];
+        uint32_t lo[R];        // ~key; 0 = empty slot (real keys are < KEY_NONE, so their ~key has the top bit set)
+        V val[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const int i = tid + j * 64;
+            V tv; int32_t tk;
+            const bool ok = get(min(i, n - 1), tv, tk) && i < n && tv == tv;     // see wg_select: loads never sit behind a branch
+            hi[j] = ok ? O::ord(tv) : 0; lo[j] = ok ? ~(uint32_t)tk : 0; val[j] = ok ? tv : (V)-INFINITY;
+        }
+        // Empty slots have hi == 0; no real value maps to 0 (ord() of a non-NaN is >= 0x007fffff).
+        auto count_ge = [&](H c) {
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < R; ++j) cnt += __popcll(O::lanes_ge(hi[j], c));
+            return cnt;
+        };
+        // 1. pivot
+        H lm = hi[0];
+#pragma unroll
+        for (int j = 1; j < R; ++j) lm = hi[j] > lm ? hi[j] : lm;
+        int lrank = 0;                      // lane maxima ranked (ties: lower lane first): a permutation of 0..63
+        for (int l = 0; l < 64; ++l) {
+            const H o = O::lane_value(lm, l);
+            lrank += (o > lm || (o == lm && l < tid)) ? 1 : 0;
+        }
+        const int pl = __ffsll((long long)__ballot(lrank == rounds - 1)) - 1;
+        H P = O::lane_value(lm, pl);
+        P = P ? P : 1;                      // fewer than `rounds` lanes hold anything: every candidate is at or above the pivot
+        // exact cut, only when the pivot lets too many through
+        bool exact = false;
+        H T = 0;
+        uint32_t TL = 0;
+        if (count_ge(P) > 64) {
+            exact = true;
+            // T = the rounds-th largest high part (0 when fewer than `rounds` candidates exist: then all of them are taken)
+            for (int bit = O::BITS - 1; bit >= 0; --bit) {
+                const H c = T | ((H)1 << bit);
+                if (count_ge(c) >= rounds) T = c;
+            }
+            // equal values straddling the cut: among hi == T keep the `need` largest low parts (= smallest keys)
+            auto count = [&](auto pred) {
+                int c = 0;
+#pragma unroll
+                for (int j = 0; j < R; ++j) c += __popcll(__ballot(pred(j)));
+                return c;
+            };
+            if (count([&](int j) { return hi[j] != 0 && hi[j] >= T; }) > rounds) {
+                const int need = rounds - count([&](int j) { return hi[j] != 0 && hi[j] > T; });
+                for (int bit = 31; bit >= 0; --bit) {
+                    const uint32_t c = TL | (1u << bit);
+                    if (count([&](int j) { return hi[j] == T && lo[j] >= c; }) >= need) TL = c;
+                }
+            }
+        }
+        // 2. compact the survivors (at most 64) into the list, in any order
+        int m = 0;
+        const uint64_t below = ((uint64_t)1 << tid) - 1;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const bool take = exact ? (hi[j] != 0 && (hi[j] > T || (hi[j] == T && lo[j] >= TL))) : hi[j] >= P;
+            const uint64_t mask = __ballot(take);
+            if (take) {
+                const int slot = m + __popcll(mask & below);
+                cv[slot] = val[j];
+                ck[slot] = (int32_t)~lo[j];
+            }
+            m += __popcll(mask);
+        }
+        // 3. one survivor per lane; its rank = number of survivors that sort before it.  (LDS executes a wave's accesses
+        // in order; the clobber only keeps the compiler from moving the cross-lane reads above the writes.)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        V mv = (V)-INFINITY;
+        int32_t mk = KEY_NONE;
+        if (tid < m) { mv = cv[tid]; mk = ck[tid]; }
+        const H mh = tid < m ? O::ord(mv) : 0;
+        const uint32_t ml = tid < m ? ~(uint32_t)mk : 0;
+        int rank = 0;
+        for (int i = 0; i < m; ++i) {
+            const H bh = O::lane_value(mh, i);
+            const uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)ml, i);
+            rank += (bh > mh || (bh == mh && bl > ml)) ? 1 : 0;
+        }
+        if (tid < m && rank < rounds) { out_v[rank] = mv; out_k[rank] = mk; }
+        if (tid >= m && tid < rounds) { out_v[tid] = (V)-INFINITY; out_k[tid] = KEY_NONE; }
     }
     __syncthreads();
 }
@@ -924,13 +1051,9 @@ __device__ __forceinline__ void wg_select_regs(int n, int rounds, F get, V *out_
 #pragma unroll
     for (int j = 0; j < R; ++j) {
         const int i = tid + j * FIN_THREADS;
-        V x = (V)-INFINITY;
-        int32_t kx = KEY_NONE;
-        if (i < n) {
-            V tv; int32_t tk;
-            if (get(i, tv, tk) && tv == tv) { x = tv; kx = tk; }
-        }
-        v[j] = x; key[j] = kx;
+        V tv; int32_t tk;
+        const bool ok = get(min(i, n - 1), tv, tk) && i < n && tv == tv;         // see wg_select: loads never sit behind a branch
+        v[j] = ok ? tv : (V)-INFINITY; key[j] = ok ? tk : KEY_NONE;
     }
     wave_rounds<V, R>(v, key, rounds, sc->pv[wave], sc->pk[wave], lane);
     __syncthreads();
@@ -951,7 +1074,11 @@ __device__ __forceinline__ void wg_select_regs(int n, int rounds, F get, V *out_
     __syncthreads();
 }
 
-// Workgroup selection over n candidates.  get(i, v, key) -> bool valid; keys unique, < KEY_NONE.
+// Workgroup selection over n >= 1 candidates.  get(i, v, key) -> bool valid; keys unique, < KEY_NONE.
+// get() is called for every register slot with an index clamped into [0, n) and must be BRANCH-FREE (select its
+// addresses, load unconditionally, return the validity): a load behind a divergent branch makes hipcc wait for it before
+// the next slot's branch, i.e. one exposed memory latency per register slot -- 16 x ~1.1 us in select_kernel's second level
+// (measured with in-kernel stamps: 20 of the kernel's 29 us).
 // n <= 4096: candidates live in registers, each wave extracts its own `rounds` winners, wave 0
 // merges the 4 lists (2 barriers in all).  Larger n: one global sweep per round (slow, rare).
 // Results land in out_v/out_k (shared memory) and are visible to every thread on return.
@@ -961,8 +1088,15 @@ __device__ void wg_select(int n, int rounds, F get, V *out_v, int32_t *out_k, Se
     constexpr int NW = FIN_THREADS / 64;
     if (n <= 64 * SEL_R) {
         // n <= 1024 (the usual case): one wave holds every candidate, no merge stage, one barrier
-        if (n <= 64 * 8) wave_select_single<V, 8>(n, rounds, get, out_v, out_k);
-        else wave_select_single<V, SEL_R>(n, rounds, get, out_v, out_k);
+        // more than a few rounds: pivot + rank-by-counting instead of serial extraction (same results)
+        const bool thresh = MMR_SEL_THRESH && rounds <= 64 && rounds >= 6;
+        if (n <= 64 * 8) {
+            if (thresh) wave_select_thresh<V, 8>(n, rounds, get, out_v, out_k);
+            else wave_select_single<V, 8>(n, rounds, get, out_v, out_k);
+        } else {
+            if (thresh) wave_select_thresh<V, SEL_R>(n, rounds, get, out_v, out_k);
+            else wave_select_single<V, SEL_R>(n, rounds, get, out_v, out_k);
+        }
         return;
     }
     if (n <= SEL_FAST_MAX) {
@@ -1031,11 +1165,11 @@ __global__ __launch_bounds__(FIN_THREADS) void select_kernel(
     __syncthreads();
     // level 2: best ks tiles among the selected tasks' tiles, ordered by (-max, +tile)
     wg_select<float>(ks * tpt, ks + 1, [&](int i, float &v, int32_t &key) {
-        const int32_t task = sel_task[i / tpt];
-        if (task == KEY_NONE) return false;
-        const int32_t tile = task * tpt + (i % tpt);
-        if (tile >= ntiles) return false;
-        v = bmax[(size_t)tile * qpad + qi]; key = tile; return true; }, sel_v, sel_tile, &scf);
+        const int slot = i / tpt;
+        const int32_t task = sel_task[slot];
+        const int32_t tile = (task == KEY_NONE ? 0 : task) * tpt + (i - slot * tpt);
+        const bool ok = task != KEY_NONE && tile < ntiles;
+        v = bmax[(size_t)(ok ? tile : 0) * qpad + qi]; key = tile; return ok; }, sel_v, sel_tile, &scf);
     if (tid < ks) sel_tiles[(size_t)qi * KS_MAX + tid] = sel_tile[tid];
     if (tid == 0) meta[qi].bound = fmaxf(bound1, sel_v[ks]);
 }
@@ -1090,12 +1224,11 @@ __global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
     const double *cs = cand + (size_t)qi * KS_MAX * TILE_ROWS;
     // candidate i = (slot i / tile_rows, row-in-tile i % tile_rows); cand keeps a 32-entry stride per slot
     wg_select<double>(ks * tile_rows, k, [&](int i, double &v, int32_t &key) {
-        const int slot = i / tile_rows, rr = i % tile_rows;
+        const int slot = i / tile_rows, rr = i - slot * tile_rows;
         const int32_t tile = st[slot];
-        if (tile == KEY_NONE) return false;
-        const int64_t row = (int64_t)tile * tile_rows + rr;
-        if (row >= N) return false;
-        key = (int32_t)row; v = cs[slot * TILE_ROWS + rr]; return true; }, out_v, out_k, &scd);
+        const int64_t row = (int64_t)(tile == KEY_NONE ? 0 : tile) * tile_rows + rr;
+        key = (int32_t)row; v = cs[slot * TILE_ROWS + rr];
+        return tile != KEY_NONE && row < N; }, out_v, out_k, &scd);
     if (tid < k) {
         const size_t o = (size_t)qi * k + tid;
         const bool has = out_k[tid] != KEY_NONE;
@@ -1202,8 +1335,7 @@ __global__ __launch_bounds__(FIN_THREADS) void exh_merge_kernel(
     const ExhEntry *p = partial + (size_t)qi * nslab * K;
     wg_select<double>(nslab * K, k, [&](int i, double &v, int32_t &key) {
         const ExhEntry e = p[i];
-        if (e.i == KEY_NONE) return false;
-        v = e.s; key = e.i; return true; }, out_v, out_k, &sc);
+        v = e.s; key = e.i; return e.i != KEY_NONE; }, out_v, out_k, &sc);
     const int tid = threadIdx.x;
     if (tid < k) {
         const size_t o = (size_t)qi * k + tid;
