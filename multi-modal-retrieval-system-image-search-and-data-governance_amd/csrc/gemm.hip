@@ -993,47 +993,59 @@ static int launch_gemm128(const bf16_t *A, const bf16_t *W, int M, int N, int K,
 // 128 x 32 x 64 tile for few rows (M <= 2048: up to 40 images / 26 texts per call -- the reference's own loops run batch
 // 1 and 10).  A 128^2 tile gives such a GEMM only (M/128) x (N/128) workgroups -- 6 .. 24 at M = 128 -- each walking the
 // whole K in one-exposed-latency steps (fc2 at M = 128: 37 us); 32-column tiles put 4x as many CUs to work and a 4-deep
-// counted-wait pipeline keeps three K-tiles in flight.  ViT-B/32 forward: batch 1 0.94 -> 0.53 ms, batch 8 0.97 -> 0.62 ms.
+// counted-wait pipeline keeps three K-tiles in flight.  ViT-B/32 forward: batch 1 0.94 -> 0.53 ms, batch 8 0.97 -> 0.62 ms
+// (0.44 ms with the 64-row tile below).
 // Waves split the rows (32 each, 2x2 MFMA tiles); every output element accumulates its K-steps in the same order as
 // in the other two kernels, so results stay bit-identical across batch sizes.
 // Epilogue: through a per-wave fp32 LDS image, then row-wise (8 lanes x 16 B = one 128-byte fp32 row segment).
 // ---------------------------------------------------------------------------------------------
+// The loop is paced by what ONE CU can ingest through LDS-DMA (~90 GB/s: 20 KiB per K-tile every 0.23 us; a 7-stage ring
+// with six K-tiles in flight measured SLOWER), so when the 128-row grid leaves CUs idle the tile is halved to 64 rows
+// (SK_BM = 64: 12 KiB per K-tile and twice the workgroups; batch 1 has 50 token rows in a 128-row tile anyway).
 constexpr int SK_BN = 32, SK_STAGES = 4;
-constexpr int SK_STAGE_BYTES = TILE_A_BYTES + SK_BN * BK * 2;      // 16 KiB + 4 KiB
-constexpr int SK_LDS = SK_STAGES * SK_STAGE_BYTES;                 // 80 KiB
+template <int SK_BM> struct SkinnyCfg {
+    static constexpr int A_BYTES = SK_BM * BK * 2;                     // 16 / 8 KiB
+    static constexpr int STAGE_BYTES = A_BYTES + SK_BN * BK * 2;       // + 4 KiB of W
+    static constexpr int LDS = SK_STAGES * STAGE_BYTES;                // 80 / 48 KiB
+};
 
-template <int EPI>
+template <int EPI, int SK_BM>
 __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
     const bf16_t *__restrict__ A, const bf16_t *__restrict__ W, int M, int N, int K,
     const float *__restrict__ bias, void *__restrict__ out)
 {
     static_assert(!epi_lnfold(EPI) && EPI != EPI_RESID_STATS_F32, "folded-LayerNorm epilogues stay on the 128^2 kernel");
+    static_assert(SK_BM == 128 || SK_BM == 64, "rows per tile");
+    constexpr int WR = SK_BM / 4;                // rows per wave: 32 / 16
+    constexpr int MI = WR / 16;                  // 16-row MFMA blocks per wave: 2 / 1
+    constexpr int AB = WR / 8;                   // 8-row staging blocks per wave: 4 / 2
+    constexpr int SK_STAGE_BYTES = SkinnyCfg<SK_BM>::STAGE_BYTES, A_BYTES = SkinnyCfg<SK_BM>::A_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int gn = N / SK_BN;
-    const int m0 = (blockIdx.x / gn) * BM;
+    const int m0 = (blockIdx.x / gn) * SK_BM;
     const int n0 = (blockIdx.x % gn) * SK_BN;
 
-    // staging: A tile = 16 blocks of 8 rows (wave w: blocks 4w .. 4w+3), W tile = 4 blocks (wave w: block w)
+    // staging: A tile = SK_BM / 8 blocks of 8 rows (wave w: blocks AB*w .. AB*w + AB-1), W tile = 4 blocks (wave w: block w)
     const int rr = lane >> 3;
     const int sc = (lane & 7) ^ rr;
-    const bf16_t *a_src = A + (size_t)(m0 + wave * 32 + rr) * K + sc * 8;
+    const bf16_t *a_src = A + (size_t)(m0 + wave * WR + rr) * K + sc * 8;
     const bf16_t *w_src = W + (size_t)(n0 + wave * 8 + rr) * K + sc * 8;
     auto stage = [&](int kt, int buf) {
         char *base = smem + buf * SK_STAGE_BYTES;
         const size_t ko = (size_t)kt * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(a_src + (size_t)i * 8 * K + ko, base + (wave * 4 + i) * 1024);
-        glds16(w_src + ko, base + TILE_A_BYTES + wave * 1024);
+        for (int i = 0; i < AB; ++i) glds16(a_src + (size_t)i * 8 * K + ko, base + (wave * AB + i) * 1024);
+        glds16(w_src + ko, base + A_BYTES + wave * 1024);
     };
-    constexpr int LPS = 5;                       // loads per wave per stage
+    constexpr int LPS = AB + 1;                  // loads per wave per stage
 
-    f32x4 acc[2][2];  // [ni][mi]
+    f32x4 acc[2][MI];  // [ni][mi]
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < MI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int fr = lane & 15, fg = lane >> 4;
     const int nkt = K / BK;
     float4 bias4[2];
@@ -1053,31 +1065,30 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
         __builtin_amdgcn_s_barrier();            // K-tile kt landed for every wave; K-tile kt-1's buffer is free
         if (kt + SK_STAGES - 1 < nkt) stage(kt + SK_STAGES - 1, (kt + SK_STAGES - 1) % SK_STAGES);
         const char *ta = smem + (kt % SK_STAGES) * SK_STAGE_BYTES;
-        const char *tw = ta + TILE_A_BYTES;
+        const char *tw = ta + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[2], wf[2];
+            bf16x8 af[MI], wf[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[i] = *reinterpret_cast<const bf16x8 *>(ta + tile_off(wave * 32 + i * 16 + fr, ks * 4 + fg));
-                wf[i] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(i * 16 + fr, ks * 4 + fg));
-            }
+            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(ta + tile_off(wave * WR + i * 16 + fr, ks * 4 + fg));
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8 *>(tw + tile_off(i * 16 + fr, ks * 4 + fg));
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], af[mi], acc[ni][mi], 0, 0, 0);
         }
     }
     __syncthreads();      // the epilogue reuses the staging buffers
 
-    // per-wave image [32 rows][8 chunks of 4 floats], chunk index XOR (row & 7)
+    // per-wave image [WR rows][8 chunks of 4 floats], chunk index XOR (row & 7)
     char *my = smem + wave * 4096;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int c = ni * 4 + fg;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             const f32x4 a = acc[ni][mi];
             const int row = mi * 16 + fr;
             *reinterpret_cast<float4 *>(my + row * 128 + ((c ^ (row & 7)) << 4)) =
@@ -1085,15 +1096,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
         }
     }
     const int rc = lane & 7, rr0 = lane >> 3;
-    const size_t row_base = (size_t)(m0 + wave * 32);
-    float4 hv[4];
+    const size_t row_base = (size_t)(m0 + wave * WR);
+    float4 hv[AB];
     if constexpr (epi_resid(EPI)) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < AB; ++i)
             hv[i] = *reinterpret_cast<const float4 *>((const float *)out + (row_base + i * 8 + rr0) * N + n0 + rc * 4);
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AB; ++i) {
         const int row = i * 8 + rr0;
         float4 v = *reinterpret_cast<const float4 *>(my + row * 128 + ((rc ^ (row & 7)) << 4));
         const size_t o = (row_base + row) * N + n0 + rc * 4;
@@ -1109,17 +1120,28 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_skinny_kernel(
     }
 }
 
+template <int EPI, int SK_BM>
+static int launch_gemm_skinny_m(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st)
+{
+    constexpr int lds = SkinnyCfg<SK_BM>::LDS;
+    static DeviceOnce once;
+    if (once.first()) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_skinny_kernel<EPI, SK_BM>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    hipLaunchKernelGGL((gemm_skinny_kernel<EPI, SK_BM>), dim3((M / SK_BM) * (N / SK_BN)), dim3(GEMM_THREADS), lds, st, A, W, M, N,
+                       K, bias, out);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
 template <int EPI>
 static int launch_gemm_skinny(const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st)
 {
-    static DeviceOnce once;
-    if (once.first()) {
-        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_skinny_kernel<EPI>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, SK_LDS));
-    }
-    hipLaunchKernelGGL(gemm_skinny_kernel<EPI>, dim3((M / BM) * (N / SK_BN)), dim3(GEMM_THREADS), SK_LDS, st, A, W, M, N, K, bias, out);
-    MMR_CHECK_LAUNCH();
-    return MMR_OK;
+    static const int force = getenv("MMR_SKINNY_ROWS") ? atoi(getenv("MMR_SKINNY_ROWS")) : 0;      // 64 / 128: A/B aid
+    // 128-row tiles would leave a third of the CUs idle (measured crossover, ViT-B/32: batch ~16)
+    const bool half = force ? force == 64 : (long long)(M / BM) * (N / SK_BN) < 160;
+    return half ? launch_gemm_skinny_m<EPI, 64>(A, W, M, N, K, bias, out, st) : launch_gemm_skinny_m<EPI, 128>(A, W, M, N, K, bias, out, st);
 }
 
 // host launcher (internal): shapes are validated by the caller in tower.hip

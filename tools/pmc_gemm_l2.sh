@@ -9,5 +9,5 @@ for set in "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" 
   tag=$(echo $set | tr ' ' '_')
   rm -rf $O/pmc_$tag
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$tag -- python tools/time_gemm.py > $O/pmc_$tag.log 2>&1 || echo "pmc $set failed"
-  for k in "mixed_kernel<0" "mixed_kernel<1" "bf16_kernel<2" "bf16_kernel<3"; do echo "== $set :: kernel ~ $k"; python tools/pmc_kernel.py $O/pmc_$tag "$k"; done
+  for k in "persist_kernel<0" "persist_kernel<1" "bf16_kernel<2" "bf16_kernel<3"; do echo "== $set :: kernel ~ $k"; python tools/pmc_kernel.py $O/pmc_$tag "$k"; done
 done
