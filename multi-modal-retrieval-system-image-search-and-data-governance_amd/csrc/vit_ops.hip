@@ -384,15 +384,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
     for (int qb = wave; qb < nqb; qb += 4) {
         const int qi = qb * 16 + fr;  // this lane's query (column of S^T)
         if (qb != wave) load_q(qb, qf);
+        // CAUSAL: key tiles past this query block's diagonal tile are masked for all 16 queries: the wave skips their
+        // MFMAs, exponentials and P.V steps (they contributed exact zeros, so the result is bit-identical); qb is wave-uniform
         f32x4 sc[NT];
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
             f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const int row = jt * 16 + fr;
+            if (!CAUSAL || jt <= qb) {
+                const int row = jt * 16 + fr;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + row * 128 + (((s * 4 + fg) ^ (row & 7)) << 4));
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
+                for (int s = 0; s < 2; ++s) {
+                    const bf16x8 kf = *reinterpret_cast<const bf16x8 *>(Ks + row * 128 + (((s * 4 + fg) ^ (row & 7)) << 4));
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[s], a, 0, 0, 0);
+                }
             }
             sc[jt] = a;
         }
@@ -400,7 +404,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         // k-slot (fg, jj) of k-step s2 <-> key 16*(2*s2 + (jj>>2)) + 4*fg + (jj&3)
         u32x2_t vraw[NT / 2][4][2];
 #pragma unroll
-        for (int s2 = 0; s2 < NT / 2; ++s2)
+        for (int s2 = 0; s2 < NT / 2; ++s2) {
+            if (CAUSAL && 2 * s2 > qb) {          // both key tiles of the pair are past the diagonal: never read, never used
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { vraw[s2][dt][0] = (u32x2_t){0, 0}; vraw[s2][dt][1] = (u32x2_t){0, 0}; }
+                continue;
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int r0 = 32 * s2 + trow;
@@ -408,10 +417,12 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
                 vraw[s2][dt][0] = lds_read_tr16(Vs + r0 * 128 + ch + 8 * (tp & 1));
                 vraw[s2][dt][1] = lds_read_tr16(Vs + (r0 + 16) * 128 + ch + 8 * (tp & 1));
             }
+        }
         // sc[jt][r] = S[query qi][key jt*16 + 4*fg + r]
         float mx = -INFINITY;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
+            if (CAUSAL && jt > qb) continue;
             int4 mk = make_int4(1, 1, 1, 1);
             if constexpr (MASKED) mk = *reinterpret_cast<const int4 *>(Ms + jt * 16 + fg * 4);
             const int mkr[4] = {mk.x, mk.y, mk.z, mk.w};
@@ -426,13 +437,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         const float m2 = mx == -INFINITY ? 0.f : mx * c2;      // scale > 0: max commutes with the scaling
         float sum = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
+        for (int jt = 0; jt < NT; ++jt) {
+            if (CAUSAL && jt > qb) continue;            // sc[jt] stays 0 = the probability of a masked key
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[jt][r], c2, -m2));
                 sc[jt][r] = p;
                 sum += p;
             }
+        }
         sum = quad_rows_reduce(sum, [](float p, float q) { return p + q; });
         const float inv = (MASKED && sum == 0.f) ? 0.f : 1.f / sum;
 
@@ -449,6 +462,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t *__restrict
         for (int dt = 0; dt < 4; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s2 = 0; s2 < NT / 2; ++s2) {
+            if (CAUSAL && 2 * s2 > qb) continue;
             union { bf16x8 v; uint32_t u[4]; } pf;
             pf.u[0] = pack_bf16x2(sc[2 * s2][0] * inv, sc[2 * s2][1] * inv);
             pf.u[1] = pack_bf16x2(sc[2 * s2][2] * inv, sc[2 * s2][3] * inv);
