@@ -157,21 +157,31 @@ __global__ __launch_bounds__(256) void embed_text_kernel(const int32_t *__restri
     if (xb) emit_fold_inputs<VPL>(x, lane, row, d, xb, stats);
 }
 
-// x_bf16[row] = LN(h[row])
-template <int VPL>
+// x_bf16[row] = LN(h[row]).  RPW rows per wave, all of their loads issued before the first reduction (several rounds of
+// waves over the chip's 8 192 wave slots otherwise pay the load latency once per round).
+template <int VPL, int RPW>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ h, const float *__restrict__ w,
                                                         const float *__restrict__ b, bf16_t *__restrict__ x, int64_t rows,
                                                         int d, float eps)
 {
     const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    float v[VPL];
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW;
+    if (row0 >= rows) return;
+    float v[RPW][VPL];
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) v[j] = h[(size_t)row * d + j * 64 + lane];
-    ln_row<VPL>(v, w, b, lane, d, eps);
+    for (int r = 0; r < RPW; ++r) {
+        const int64_t row = row0 + r < rows ? row0 + r : rows - 1;      // a ragged last wave re-reads the last row
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) x[(size_t)row * d + j * 64 + lane] = f32_to_bf16(v[j]);
+        for (int j = 0; j < VPL; ++j) v[r][j] = h[(size_t)row * d + j * 64 + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        ln_row<VPL>(v[r], w, b, lane, d, eps);
+        if (row0 + r < rows) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) x[(size_t)(row0 + r) * d + j * 64 + lane] = f32_to_bf16(v[r][j]);
+        }
+    }
 }
 
 // BERT embeddings (transformers/models/bert/modeling_bert.py:53-108): word[ids] + type[0] + pos[t] -> LayerNorm
@@ -764,8 +774,16 @@ int launch_layernorm(const float *h, const float *w, const float *b, bf16_t *x, 
                      hipStream_t st)
 {
     ProfScope prof(MMR_PROF_ROWWISE, st);
-    const dim3 grid((unsigned)((rows + 3) / 4));
-    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(layernorm_kernel<VPL>, grid, dim3(256), 0, st, h, w, b, x, rows, d, eps));
+    static const int force_rpw = getenv("MMR_LN_RPW") ? atoi(getenv("MMR_LN_RPW")) : 0;      // 1 / 2: A/B aid
+    // measured: no change at 12 800 rows (ViT-B/32 batch 256), -6 % at 73 856 rows (ViT-L/14@336 batch 128)
+    const bool two = force_rpw ? force_rpw == 2 : rows >= 32768;
+    if (two) {
+        const dim3 grid((unsigned)((rows + 7) / 8));
+        MMR_VPL_SWITCH(d, hipLaunchKernelGGL((layernorm_kernel<VPL, 2>), grid, dim3(256), 0, st, h, w, b, x, rows, d, eps));
+    } else {
+        const dim3 grid((unsigned)((rows + 3) / 4));
+        MMR_VPL_SWITCH(d, hipLaunchKernelGGL((layernorm_kernel<VPL, 1>), grid, dim3(256), 0, st, h, w, b, x, rows, d, eps));
+    }
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
