@@ -593,14 +593,23 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
     gload(0);
     lwrite(0);
     __syncthreads();
-    for (int kb = 0; kb < nkb; ++kb) {
+    // One key block.  TAIL = the sequence's last block, which may hold as little as ONE valid key (T = 577 = 9 x 64 + 1):
+    // only its first njt 16-key tiles are multiplied, exponentiated and fed to P.V (the rest contributed exact zeros).
+    auto block = [&](int kb, auto tailc) {
+        constexpr bool TAIL = decltype(tailc)::value;
         const int buf = kb & 1;
-        if (kb + 1 < nkb) gload(kb + 1);       // in flight during this block's MFMAs
+        if constexpr (!TAIL) gload(kb + 1);    // in flight during this block's MFMAs
+        const int njt = TAIL ? (T - kb * AKB + 15) / 16 : 4;       // wave-uniform
         const char *Ks = smem + buf * ABUF, *Vs = Ks + AIMG;
 
         f32x4 sc[QB][4];
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) {
+            if (TAIL && jt >= njt) {
+#pragma unroll
+                for (int x = 0; x < QB; ++x) sc[x][jt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
             const int row = jt * 16 + fr;
             bf16x8 kf[2];
 #pragma unroll
@@ -618,7 +627,12 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
         // the MFMA's k slots 8*fg .. 8*fg+7 are keys 32*s2 + 4*fg + {0..3} and 32*s2 + 16 + 4*fg + {0..3}
         u32x2_t vraw[2][4][2];                 // [s2][dt][half]; not to be touched before the wait below
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
+        for (int s2 = 0; s2 < 2; ++s2) {
+            if (TAIL && 2 * s2 >= njt) {
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) { vraw[s2][dt][0] = (u32x2_t){0, 0}; vraw[s2][dt][1] = (u32x2_t){0, 0}; }
+                continue;
+            }
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
                 const int r0 = 32 * s2 + trow;
@@ -626,10 +640,12 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
                 vraw[s2][dt][0] = lds_read_tr16(Vs + r0 * 128 + ch + 8 * (tp & 1));
                 vraw[s2][dt][1] = lds_read_tr16(Vs + (r0 + 16) * 128 + ch + 8 * (tp & 1));
             }
+        }
         // keys past T (last block only) and, for the causal form, keys after the query
-        if (CAUSAL || MASKED || kb == nkb - 1) {
+        if (CAUSAL || MASKED || TAIL) {
 #pragma unroll
             for (int jt = 0; jt < 4; ++jt) {
+                if (TAIL && jt >= njt) continue;
                 int4 mk = make_int4(1, 1, 1, 1);
                 if constexpr (MASKED) mk = *reinterpret_cast<const int4 *>(Ms + buf * AKB + jt * 16 + fg * 4);
                 const int mkr[4] = {mk.x, mk.y, mk.z, mk.w};
@@ -649,7 +665,8 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
             float bm = fmaxf(fmaxf(sc[x][0][0], sc[x][0][1]), fmaxf(sc[x][0][2], sc[x][0][3]));
 #pragma unroll
             for (int jt = 1; jt < 4; ++jt)
-                bm = fmaxf(bm, fmaxf(fmaxf(sc[x][jt][0], sc[x][jt][1]), fmaxf(sc[x][jt][2], sc[x][jt][3])));
+                if (!TAIL || jt < njt)
+                    bm = fmaxf(bm, fmaxf(fmaxf(sc[x][jt][0], sc[x][jt][1]), fmaxf(sc[x][jt][2], sc[x][jt][3])));
             bm = quad_rows_reduce(bm, [](float p, float q) { return fmaxf(p, q); });
             const float mn = fmaxf(m[x], bm * c2);                // scale > 0: max commutes with the scaling
             const float msafe = mn == -INFINITY ? 0.f : mn;       // fully masked so far (causal padding rows)
@@ -658,13 +675,15 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
             m[x] = mn;
             float ps = 0.f;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+            for (int jt = 0; jt < 4; ++jt) {
+                if (TAIL && jt >= njt) continue;                  // sc stays 0 = the probability of a key past T
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[x][jt][r], c2, -msafe));
                     sc[x][jt][r] = p;
                     ps += p;
                 }
+            }
             l[x] = l[x] * alpha[x] + ps;
         }
         if (__any(moved)) {                    // wave-uniform: rescale only when some query's running max moved
@@ -692,6 +711,7 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
                 vf[s2][dt] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vraw[s2][dt][0], vraw[s2][dt][1], 0, 1, 2, 3));
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+            if (TAIL && 2 * s2 >= njt) continue;
             union { bf16x8 v; uint32_t u[4]; } pf[QB];
 #pragma unroll
             for (int x = 0; x < QB; ++x) {
@@ -706,9 +726,13 @@ __global__ __launch_bounds__(256) void attention_stream_kernel(const bf16_t *__r
                 for (int x = 0; x < QB; ++x)
                     oacc[x][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[s2][dt], pf[x].v, oacc[x][dt], 0, 0, 0);
         }
-        if (kb + 1 < nkb) lwrite(buf ^ 1);     // the other buffer was last read in iteration kb-1
-        __syncthreads();
-    }
+        if constexpr (!TAIL) {
+            lwrite(buf ^ 1);                   // the other buffer was last read in iteration kb-1
+            __syncthreads();
+        }
+    };
+    for (int kb = 0; kb + 1 < nkb; ++kb) block(kb, std::false_type{});
+    block(nkb - 1, std::true_type{});
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
         const float lx = quad_rows_reduce(l[x], [](float p, float q) { return p + q; });
