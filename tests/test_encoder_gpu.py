@@ -174,6 +174,40 @@ def test_attention_core(L, device, T, causal):
     assert err <= 1.3e-2 * ref.abs().max().item() + 1e-4, f"T={T} causal={causal}: {err / ref.abs().max().item():.2e} of max"
 
 
+@pytest.mark.parametrize("T,causal,masked", [(257, 0, 0), (577, 0, 0), (200, 1, 0), (300, 0, 1)])
+def test_attention_large_batch_matches_small_batch_bitwise(L, device, T, causal, masked):
+    """A launch over many sequences (thousands of workgroups, whatever work assignment the launcher picks at that size)
+    returns the same bits per sequence as a three-sequence launch, and stays within the usual bound of the fp32 reference."""
+    B, heads = 104, 8
+    d = heads * 64
+    g = torch.Generator().manual_seed(7 * T + causal)
+    qkv = (torch.randn(B * T, 3 * d, generator=g) * 1.5).bfloat16().to(device)
+    mask = None
+    if masked:
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        mask = (torch.arange(T)[None, :] < lens[:, None]).int().to(device)
+
+    def run(nb):
+        o = torch.zeros(nb * T, d, dtype=torch.bfloat16, device=device)
+        if masked:
+            L.check(L.lib().mmr_debug_attention_masked(qkv.data_ptr(), o.data_ptr(), nb, T, heads, mask.data_ptr(), L.stream_ptr(device)))
+        else:
+            L.check(L.lib().mmr_debug_attention(qkv.data_ptr(), o.data_ptr(), nb, T, heads, causal, L.stream_ptr(device)))
+        return o
+
+    big, small = run(B), run(3)
+    assert torch.equal(big[:3 * T], small)
+    q, k, v = qkv.float().view(B, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        att = att + torch.full((T, T), float("-inf"), device=device).triu(1)
+    if masked:
+        att = att.masked_fill(mask.view(B, 1, 1, T) == 0, float("-inf"))
+    ref = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(B * T, d)
+    err = (big.float() - ref).abs().max().item()
+    assert err <= 1.3e-2 * ref.abs().max().item() + 1e-4, f"T={T}: {err / ref.abs().max().item():.2e} of max"
+
+
 @pytest.mark.parametrize("T", [1, 19, 50, 64, 77, 96, 97, 130, 257, 300, 512])
 def test_attention_core_with_key_padding_mask(L, device, T):
     """The non-causal kernels with HF's key-padding `attention_mask` (BERT text tower with padded batches)."""
