@@ -240,6 +240,36 @@ def test_error_paths(S, device):
 
 
 @pytest.mark.slow
+def test_selection_when_the_best_tasks_crowd_into_few_lanes(S, oracle, device):
+    """select_kernel ranks its candidates (505 scan tasks at 1M rows, candidate i in lane i % 64) from a pivot = the
+    (KS+1)-th largest per-lane maximum; when the strong candidates sit in fewer lanes than that, more than 64 candidates
+    pass the pivot and the bitwise search for the exact cut takes over.  64 strong rows, one in every task t with
+    t % 64 < 8, graded so that the top-10 is unambiguous; a second query is plain random."""
+    N, E, k = 1_000_000, 512, 10
+    gal = synth.synth_unit_rows(N, E, seed=13, dtype=torch.bfloat16)
+    q = synth.synth_unit_rows(2, E, seed=14, dtype=torch.bfloat16)
+    rows_per_task = 62 * 32                                  # make_plan(): 31 250 tiles -> 62 tiles per task, 505 tasks
+    planted = []
+    g = torch.Generator().manual_seed(15)
+    for j, t in enumerate(t for t in range(505) if t % 64 < 8):
+        r = t * rows_per_task + 5 + (j % 7) * 32
+        noise = torch.randn(E, generator=g)
+        q0 = q[0].float() / q[0].float().norm()
+        noise = noise - (noise @ q0) * q0                    # orthogonal to the query: the cosine is set by w alone
+        noise = noise / noise.norm()
+        w = 0.45 + 0.006 * j                                 # cosines 0.91 .. 0.74, about 0.003 apart
+        v = q[0].float() * (1 - w * w) ** 0.5 + noise * w
+        gal[r] = (v / v.norm()).bfloat16()
+        planted.append(r)
+    index = S.GalleryIndex(gal.to(device))
+    vals, idx, d64, status = index.search(q.to(device), k, return_dot64=True, return_status=True)
+    oi, _, od = oracle.cosine_topk(q, gal, k)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d64.cpu().numpy(), od)
+    assert idx[0].tolist() == planted[:k]
+    assert int(status.sum()) == 0                            # nothing near the cut: both queries certify on the fast path
+
+
+@pytest.mark.slow
 @pytest.mark.parametrize("N,E,Q", [(1_000_000, 512, 256),      # BASELINE configs[1]/[2]: the 1M x 512 gallery
                                    (1_250_000, 512, 256),      # configs[3]: one GPU's shard of the 10M gallery
                                    (1_000_000, 768, 128)])     # configs[4]: the E = 768 (ViT-L/14) shard
