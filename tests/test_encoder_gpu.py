@@ -56,7 +56,11 @@ def _check_cos(got, want, what, fold=False):
                                    (9216, 1024, 64),        # 36 panels x 4 = 144 tiles of 256x256
                                    (19712, 512, 192),       # text tower out-proj at 256 prompts: 77 panels x 2
                                    (12928, 768, 128),       # rows a multiple of 128 but not of 256: 128x128 tiles
-                                   (6400, 768, 64),         # batch 128: 25 panels x 4 of 256x192
+                                   (6400, 768, 64),         # batch 128 out-proj: too few 256-row tiles -> 128x128 tiles
+                                   (4864, 2304, 128),       # batch 96 qkv: rows not a multiple of 256
+                                   (3200, 768, 3072),       # batch 64 fc2: 48 K-tiles
+                                   (9600, 3072, 64),        # batch 192 fc1
+                                   (2432, 768, 64),         # batch 48: 19 panels of 128 rows
                                    (2304, 384, 128), (3072, 768, 3072),     # 128x128 tiles (M > 2048, too few 256-row tiles)
                                    (2048, 128, 64), (128, 3072, 768)])      # 128x32 tiles at both ends of their range
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5, 6])
@@ -102,7 +106,8 @@ def test_gemm_epilogues(L, device, M, N, K, epi):
     assert excess <= 1.0, f"gemm epi={epi} {M}x{N}x{K}: error is {excess:.2f}x the per-element bound"
 
 
-@pytest.mark.parametrize("M,N,K", [(12928, 768, 128), (19712, 512, 64), (6400, 768, 64), (12800, 768, 64)])
+@pytest.mark.parametrize("M,N,K", [(12928, 768, 128), (19712, 512, 64), (6400, 768, 64), (12800, 768, 64), (4864, 2304, 64),
+                                   (3200, 768, 128)])
 @pytest.mark.parametrize("epi", [0, 2])
 def test_gemm_stays_inside_its_operands(L, device, M, N, K, epi):
     """Whatever tile shape the launcher picks, nothing past row M of A may reach the result (A is followed by NaN rows) and
