@@ -1164,11 +1164,14 @@ __global__ __launch_bounds__(FIN_THREADS) void select_kernel(
     const float bound1 = sel_v[ks];  // -inf when no task was left out
     __syncthreads();
     // level 2: best ks tiles among the selected tasks' tiles, ordered by (-max, +tile)
-    wg_select<float>(ks * tpt, ks + 1, [&](int i, float &v, int32_t &key) {
-        const int slot = i / tpt;
+    // candidate i = (selected task i / 64, tile i % 64 of it): tasks hold at most MAX_TPT = 64 tiles, so the index splits
+    // with a shift instead of a division by the run-time tile count (16 divisions per lane were ~1 us of this kernel)
+    static_assert(MAX_TPT == 64, "candidate index layout");
+    wg_select<float>(ks * MAX_TPT, ks + 1, [&](int i, float &v, int32_t &key) {
+        const int slot = i >> 6, t = i & 63;
         const int32_t task = sel_task[slot];
-        const int32_t tile = (task == KEY_NONE ? 0 : task) * tpt + (i - slot * tpt);
-        const bool ok = task != KEY_NONE && tile < ntiles;
+        const int32_t tile = (task == KEY_NONE ? 0 : task) * tpt + t;
+        const bool ok = task != KEY_NONE && t < tpt && tile < ntiles;
         v = bmax[(size_t)(ok ? tile : 0) * qpad + qi]; key = tile; return ok; }, sel_v, sel_tile, &scf);
     if (tid < ks) sel_tiles[(size_t)qi * KS_MAX + tid] = sel_tile[tid];
     if (tid == 0) meta[qi].bound = fmaxf(bound1, sel_v[ks]);
@@ -1223,8 +1226,9 @@ __global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
     const int32_t *st = sel_tiles + (size_t)qi * KS_MAX;
     const double *cs = cand + (size_t)qi * KS_MAX * TILE_ROWS;
     // candidate i = (slot i / tile_rows, row-in-tile i % tile_rows); cand keeps a 32-entry stride per slot
+    const int tr_shift = tile_rows == 32 ? 5 : 4;                     // tile_rows is 32 (bf16) or 16 (fp32)
     wg_select<double>(ks * tile_rows, k, [&](int i, double &v, int32_t &key) {
-        const int slot = i / tile_rows, rr = i - slot * tile_rows;
+        const int slot = i >> tr_shift, rr = i & (tile_rows - 1);
         const int32_t tile = st[slot];
         const int64_t row = (int64_t)(tile == KEY_NONE ? 0 : tile) * tile_rows + rr;
         key = (int32_t)row; v = cs[slot * TILE_ROWS + rr];
