@@ -881,10 +881,13 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
 
 static int tile_group_panels(int gn)
 {
-    // panels per tile-order group: the concurrent set of one XCD (32 CUs) should be near-square, at most 6 columns wide
+    // panels per tile-order group.  Round 1 sized it so that one XCD's concurrent set (32 CUs) is near-square (6 .. 8
+    // panels); measured in situ on the forward, groups of 4 panels are 0.5-1.9 % faster on every tower (ViT-B/32 GEMM time
+    // 2.45 -> 2.40 ms, ViT-L/14@336 40.4 -> 40.2 ms; three boxes, alternating runs): the workgroups of an XCD drift apart
+    // over a round, and a narrower group keeps the A panels they share closer together in time.
     static const int force_pg = getenv("MMR_GEMM_PG") ? atoi(getenv("MMR_GEMM_PG")) : 0;
-    const int cols = gn < 6 ? gn : 6;
-    return force_pg > 0 ? force_pg : (32 + cols - 1) / cols;
+    (void)gn;
+    return force_pg > 0 ? force_pg : 4;
 }
 
 template <int EPI, int NIW, bool PATCH = false>
