@@ -5,6 +5,16 @@
     python bench.py --config cfg4                                       # one GPU's share of configs[3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W [--config cfgX]
+    python bench.py --gpus N [...]                                      # same thing without a launcher: see below
+    python bench.py --gpus 1 --spawn                                    # the N > 1 code path (process group, RCCL
+                                                                        # all-gather, pipelined steps) with ONE rank
+
+Launching.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) each process is one rank.  Called
+plainly with --gpus N > 1 (or with --spawn), this process becomes a PARENT that never touches the GPU: it picks a free
+port on 127.0.0.1, starts N fresh children of this same file with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (plain
+subprocesses -- no exec of a process that has initialised the GPU), relays rank 0's single JSON line, and exits non-zero
+if any child does (the others are then stopped by PID).  A rank whose GPU index does not exist on the node exits with a
+device-count message, so `--gpus 2` on a one-GPU box fails clearly instead of hanging in the rendezvous.
 
 Workloads (--config; names follow SURVEY.md section 8d; per RANK, weak scaling -- fixed per-GPU work):
   cfg2  BASELINE configs[1]: ViT-B/32 bf16 encode of 256 images + top-10 of 256 queries over 1M x 512 bf16 rows
@@ -36,7 +46,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+torch = None  # imported by main() AFTER the launch decision: the parent of self-spawned ranks never needs it
 
 TOPK = 10
 # dense peaks from /opt/skills/guides/MI355X_MICROARCH.md (spec): bf16 MFMA ~2.5 PFLOP/s, HBM3E 8 TB/s
@@ -125,55 +135,52 @@ def unit_rows_on_device(n, e, seed, dev):
     return out
 
 
-def verify_sharded(index, sharded, gal, queries, k, dev, dist, use_dist):
-    """Proof that the merged list is the exact global top-k (outside the timed region; collectives allowed).
-    Returns ("ok", details) or ("FAILED: ...", details)."""
-    qd = queries.double()
-    if sharded:
-        score, gidx, d64 = index.search_async(queries, k, 1.0).result(return_dot64=True)
-        offset, n_local = index.offset, gal.shape[0]
-        local = index._index
-    else:
-        score, gidx, d64 = index.search(queries, k, 1.0, return_dot64=True)
-        offset, n_local = 0, gal.shape[0]
-        local = index
-    Q = queries.shape[0]
-    problems = []
-    # (a) every returned id re-scored by the rank that owns it
-    mine = (gidx >= offset) & (gidx < offset + n_local)
-    rows = gal[(gidx - offset).clamp(0, n_local - 1).reshape(-1)].double().reshape(Q, k, -1)
-    re = (rows * qd.unsqueeze(1)).sum(-1)
-    re = torch.where(mine, re, torch.zeros_like(re))
-    owners = mine.to(torch.int32)
-    if use_dist:
-        dist.all_reduce(re)
-        dist.all_reduce(owners)
-    if not bool((owners == 1).all()):
-        problems.append("an id is owned by no rank or by several")
-    err = float((re - d64).abs().max())
-    if not err < 1e-12:
-        problems.append(f"re-scored dot differs from the merged dot64 by {err:.3e}")
-    # (b) order and uniqueness
-    if not bool(((d64[:, :-1] > d64[:, 1:]) | ((d64[:, :-1] == d64[:, 1:]) & (gidx[:, :-1] < gidx[:, 1:]))).all()):
-        problems.append("merged list is not in (-dot, +id) order")
-    # (c) nothing outside the candidates can beat the k-th: merged k-th >= every rank's local (k+1)-th
-    _, _, ld = local.search(queries, k + 1, 1.0, return_dot64=True)
-    nxt = ld[:, k].clone()
-    if use_dist:
-        dist.all_reduce(nxt, op=dist.ReduceOp.MAX)
-    if not bool((d64[:, k - 1] >= nxt).all()):
-        problems.append("a rank's local (k+1)-th row beats the merged k-th")
-    # (d) all ranks hold the same answer
-    if use_dist:
-        chk = torch.stack([gidx.double().sum(), d64.sum()])
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        if not bool((lo == hi).all()):
-            problems.append("ranks disagree on the merged result")
-    detail = {"rescored_max_abs_err": err, "queries": Q, "k": k,
-              "checks": "owner re-score == merged dot64; (-dot,+id) order; merged k-th >= every local (k+1)-th; ranks agree"}
-    return ("ok" if not problems else "FAILED: " + "; ".join(problems)), detail
+def spawn_ranks(n, argv):
+    """Parent of self-started ranks (module docstring, "Launching").  Never imports torch, never touches the GPU."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    child_argv = [a for a in argv if a != "--spawn"]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), MMR_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs across processes on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + child_argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+    rc, out0 = 0, b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                if r == 0:
+                    try:
+                        o, _ = procs[0].communicate(timeout=0.2)     # drains the pipe while waiting
+                        out0 += o
+                    except subprocess.TimeoutExpired:
+                        continue
+                else:
+                    try:
+                        procs[r].wait(timeout=0.2)
+                    except subprocess.TimeoutExpired:
+                        continue
+                pending.discard(r)
+                if procs[r].returncode != 0 and rc == 0:
+                    rc = procs[r].returncode or 1
+                    print(f"bench.py: rank {r} exited with code {procs[r].returncode}; stopping the other ranks", file=sys.stderr)
+                    for j in pending:                               # exact PIDs we started, nothing by pattern
+                        procs[j].terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    raise SystemExit(rc if rc >= 0 else 1)
 
 
 def main():
@@ -188,7 +195,17 @@ def main():
     ap.add_argument("--queries", type=int, default=None, help="override queries per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks from this process (implied by --gpus N > 1 without a launcher); with --gpus 1 it "
+                         "rehearses the process-group / all-gather path on one GPU")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and (args.gpus > 1 or args.spawn):
+        spawn_ranks(args.gpus, sys.argv[1:])            # does not return
+
+    global torch
+    import torch
 
     # Native libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on
     # stdout, so everything else is routed to stderr and the JSON goes to the saved descriptor.
@@ -210,10 +227,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s) (WORLD_SIZE={world})")
+    ndev = torch.cuda.device_count()                     # does not initialise the GPU
+    if ndev == 0:
         raise SystemExit("bench.py needs an MI355X; there is no CPU path (the CPU oracle is only the baseline leg)")
+    if local_rank >= ndev:
+        raise SystemExit(f"bench.py: rank {rank} of {world} needs GPU index {local_rank}, but this node exposes {ndev} device(s): "
+                         f"--gpus {args.gpus} wants one MI355X per rank (RCCL does not run two ranks on one device)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -309,7 +330,7 @@ def main():
 
     # ---- outside the timed region: verification, fallback count, query sweep
     vq = encode() if ENC == "text" else queries
-    verify, verify_detail = verify_sharded(index, use_dist, gal, vq, TOPK, dev, dist, use_dist)
+    verify, verify_detail = search.verify_exact_topk(index, gal, vq, TOPK)
     local_index = index._index if use_dist else index
     status = local_index.search(vq, TOPK, 1.0, return_status=True)[-1]
     fallback = int(status.sum())
@@ -383,7 +404,13 @@ def main():
             "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "traffic_source": traffic_src,
             "avg_launch_us": round(gemm_ms / gemm_n * 1e3, 2) if gemm_n else None, "launches": gemm_n,
             "algorithmic_gflop_per_launch": round(gflops / n_gemm / 1e9, 3) if n_gemm else None,
-            "measured": "HIP event pairs around each launch on the launch stream, second pass of the same K steps",
+            "measured": "HIP event pairs around each launch on the launch stream, second pass of the same K steps "
+                        "(event pairs inflate every launch: `frac` is a floor)",
+            # the same algorithmic GEMM FLOPs over the UN-instrumented encode time of the timed region (which also holds the
+            # LayerNorm / attention / row kernels): the end-to-end figure; the kernel-level truth lies between the two and is
+            # what profiles/*_kernel_stats.csv (rocprofv3) gives
+            "uninstrumented_encode_tflops": round(gflops / (enc_ms * 1e-3) / 1e12, 2) if enc_ms > 0 else None,
+            "uninstrumented_encode_frac": round(gflops / (enc_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if enc_ms > 0 else None,
         }
         roof_scan = {
             "kernel": f"scan_kernel<{EMBED}>", "bound": "hbm+mfma",
@@ -408,7 +435,9 @@ def main():
                        "encode_batch_per_gpu": BATCH, "gallery_rows_per_gpu": ROWS, "gallery_rows_total": ROWS * world,
                        "queries": QUERIES, "k": TOPK, "embed_dim": EMBED,
                        "parallelism": (f"dp{world} encode (no collective), gallery row-sharded x{world}, 1 async all-gather of "
-                                       f"top-k per step overlapped with the next step") if world > 1 else "single GPU",
+                                       f"top-k per step overlapped with the next step") if use_dist else "single GPU",
+                       "launch": ("self-spawned ranks" if os.environ.get("MMR_BENCH_SPAWNED") else
+                                  "torch.distributed.run" if use_dist else "single process"),
                        "weights": "seeded random init (no checkpoint reachable offline)"},
             "verify": verify, "verify_detail": verify_detail,
             "search_fallback_queries": fallback,

@@ -97,10 +97,17 @@ int mmr_topk_merge_packed(const int64_t *packed_parts, int parts, int Q, int k, 
                           double *dot64, void *stream);
 
 /* Multi-GPU leg for hosts without torch.distributed: one process per GPU; rank r searches its
- * gallery rows with mmr_cosine_topk(_ex), adds its row offset to the ids (int64, -1 stays -1), then ONE RCCL all-gather
- * over xGMI of the per-shard (id, fp64 dot) lists and mmr_topk_merge.  librccl is bound at run time (dlopen; MMR_RCCL_LIB
- * overrides the name), so a single-GPU user needs no RCCL.  The Python package performs the same exchange through
- * torch.distributed's "nccl" (= RCCL) backend (search.ShardedGalleryIndex). */
+ * gallery rows with mmr_cosine_topk(_ex), packs its list with mmr_topk_pack(row_offset = first global row of the shard),
+ * then ONE RCCL all-gather over xGMI of the packed messages (mmr_allgather_topk_packed) and mmr_topk_merge_packed:
+ *
+ *     mmr_cosine_topk_ex(q, shard, ..., idx32, score, dot64, ...);          // local top-k, int32 local ids
+ *     mmr_topk_pack(idx32, dot64, Q, k, row_offset, packed, stream);        // [Q,k,2] int64 = (global id | -1, dot bits)
+ *     mmr_allgather_topk_packed(comm, packed, Q, k, parts, stream);         // [world,Q,k,2]   -- the collective
+ *     mmr_topk_merge_packed(parts, world, Q, k, scale, idx64, score, dot64, stream);
+ *
+ * librccl is bound at run time (dlopen; MMR_RCCL_LIB overrides the name), so a single-GPU user needs no RCCL.  The Python
+ * package performs the SAME exchange (one message of 2*Q*k int64 per rank) through torch.distributed's "nccl" (= RCCL)
+ * backend (search.ShardedGalleryIndex.search_async). */
 typedef struct mmr_comm mmr_comm;
 #define MMR_COMM_ID_BYTES 128
 /* rank 0: fill MMR_COMM_ID_BYTES bytes of HOST memory; the host program hands them to every rank (file, socket, MPI ...) */
@@ -108,8 +115,11 @@ int mmr_comm_unique_id(void *id_host);
 /* collective over all ranks; binds the communicator to the calling thread's current HIP device */
 int mmr_comm_init(int rank, int world, const void *id_host, mmr_comm **out);
 void mmr_comm_destroy(mmr_comm *c);
-/* idx_local / dot_local [Q,k] (device) -> idx_parts / dot_parts [world,Q,k] (device), asynchronous on `stream`;
- * the two arrays travel as one fused collective.  Feed the result to mmr_topk_merge(parts = world). */
+/* packed_local [Q,k,2] int64 (device, mmr_topk_pack layout) -> packed_parts [world,Q,k,2] (device), asynchronous on
+ * `stream`: ONE ncclAllGather.  Feed the result to mmr_topk_merge_packed(parts = world). */
+int mmr_allgather_topk_packed(mmr_comm *c, const int64_t *packed_local, int Q, int k, int64_t *packed_parts, void *stream);
+/* Unpacked form (kept for callers that hold separate arrays): idx_local / dot_local [Q,k] (device, GLOBAL int64 ids) ->
+ * idx_parts / dot_parts [world,Q,k]; the two arrays travel as one grouped pair of all-gathers.  -> mmr_topk_merge. */
 int mmr_allgather_topk(mmr_comm *c, const int64_t *idx_local, const double *dot_local, int Q, int k,
                        int64_t *idx_parts, double *dot_parts, void *stream);
 

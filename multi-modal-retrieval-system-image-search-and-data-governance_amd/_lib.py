@@ -75,6 +75,8 @@ def lib():
     L.mmr_comm_destroy.argtypes = [vp]
     L.mmr_allgather_topk.restype = i32
     L.mmr_allgather_topk.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    L.mmr_allgather_topk_packed.restype = i32
+    L.mmr_allgather_topk_packed.argtypes = [vp, vp, i32, i32, vp, vp]
     L.mmr_tip_adapter_logits.restype = i32
     L.mmr_tip_adapter_logits.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, i32, f32, f32, vp, vp, vp]
     L.mmr_preprocess_image.restype = i32

@@ -120,6 +120,21 @@ extern "C" void mmr_comm_destroy(mmr_comm *c)
     delete c;
 }
 
+extern "C" int mmr_allgather_topk_packed(mmr_comm *c, const int64_t *packed_local, int Q, int k, int64_t *packed_parts,
+                                         void *stream)
+{
+    MMR_CHECK_ARG(c != nullptr, "mmr_allgather_topk_packed: null communicator");
+    MMR_CHECK_ARG(Q >= 0 && k >= 1, "mmr_allgather_topk_packed: bad shape Q=%d k=%d", Q, k);
+    if (Q == 0) return MMR_OK;
+    MMR_CHECK_ARG(packed_local && packed_parts, "mmr_allgather_topk_packed: null pointer");
+    const Rccl *R = rccl();
+    if (!R) { mmr::set_error("mmr_allgather_topk_packed: librccl not found"); return MMR_ENOTSUP; }
+    // THE collective of the sharded search: one message of 2*Q*k int64 per rank -- the same exchange
+    // search.ShardedGalleryIndex issues through torch.distributed (all_gather_into_tensor of the packed tensor)
+    MMR_CHECK_NCCL(R->all_gather(packed_local, packed_parts, (size_t)Q * k * 2, NCCL_INT64, c->comm, (hipStream_t)stream));
+    return MMR_OK;
+}
+
 extern "C" int mmr_allgather_topk(mmr_comm *c, const int64_t *idx_local, const double *dot_local, int Q, int k,
                                   int64_t *idx_parts, double *dot_parts, void *stream)
 {
@@ -130,10 +145,21 @@ extern "C" int mmr_allgather_topk(mmr_comm *c, const int64_t *idx_local, const d
     const Rccl *R = rccl();
     if (!R) { mmr::set_error("mmr_allgather_topk: librccl not found"); return MMR_ENOTSUP; }
     const size_t n = (size_t)Q * k;
-    // the two payload arrays travel as ONE fused collective (a group of two all-gathers of 8-byte elements)
+    // the two payload arrays travel as ONE fused collective (a group of two all-gathers of 8-byte elements).
+    // A failure between ncclGroupStart and ncclGroupEnd must still close the group: a thread left in group mode
+    // queues every later RCCL call (torch's included) without ever launching it.  The FIRST error is reported.
     MMR_CHECK_NCCL(R->group_start());
-    MMR_CHECK_NCCL(R->all_gather(idx_local, idx_parts, n, NCCL_INT64, c->comm, (hipStream_t)stream));
-    MMR_CHECK_NCCL(R->all_gather(dot_local, dot_parts, n, NCCL_FLOAT64, c->comm, (hipStream_t)stream));
-    MMR_CHECK_NCCL(R->group_end());
+    int e = R->all_gather(idx_local, idx_parts, n, NCCL_INT64, c->comm, (hipStream_t)stream);
+    const char *what = "ncclAllGather(idx)";
+    if (e == 0) {
+        e = R->all_gather(dot_local, dot_parts, n, NCCL_FLOAT64, c->comm, (hipStream_t)stream);
+        what = "ncclAllGather(dot)";
+    }
+    const int e_end = R->group_end();
+    if (e == 0 && e_end != 0) { e = e_end; what = "ncclGroupEnd"; }
+    if (e != 0) {
+        mmr::set_error("mmr_allgather_topk: %s failed: %s", what, R->error_string ? R->error_string(e) : "RCCL error");
+        return MMR_EIO;
+    }
     return MMR_OK;
 }

@@ -206,6 +206,11 @@ class GalleryIndex:
     scores it against reference vectors; rows are whatever ``encode_image`` produced -- normalised or
     not: the largest row norm is measured once here (device scalar, no host sync) and sizes the
     certificate's margin; a caller-supplied ``norm_bound`` can only widen it.
+
+    The exactness certificate rests on that measured bound, so ``self.gallery`` is treated as FROZEN after
+    construction: change rows through ``update_rows`` (writes them and re-measures) or call
+    ``refresh_norm_bound()`` after writing into ``self.gallery`` yourself -- an in-place update that raises a
+    row norm without a re-measure would understate the bound and could let the certificate pass wrongly.
     """
 
     def __init__(self, gallery: torch.Tensor, norm_bound: Optional[float] = None):
@@ -221,6 +226,19 @@ class GalleryIndex:
     @property
     def num_rows(self) -> int:
         return self.gallery.shape[0]
+
+    def refresh_norm_bound(self) -> None:
+        """Re-measure the largest row norm into the SAME device scalar (one HBM-bound pass, no host sync), so searches
+        already captured in a hipGraph see the new bound too."""
+        g = self.gallery
+        L = _lib.lib()
+        _lib.check(L.mmr_gallery_norm_bound(g.data_ptr(), _lib.dtype_code(g.dtype), g.shape[0], g.shape[1],
+                                            self.norm_bound_dev.data_ptr(), _lib.stream_ptr(g.device)))
+
+    def update_rows(self, rows: torch.Tensor, values: torch.Tensor) -> None:
+        """``gallery[rows] = values`` followed by a re-measure of the norm bound (keeps the certificate sound)."""
+        self.gallery[rows.to(self.gallery.device)] = values.to(device=self.gallery.device, dtype=self.gallery.dtype)
+        self.refresh_norm_bound()
 
     def search(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0, return_dot64: bool = False,
                return_status: bool = False):
@@ -361,3 +379,82 @@ class ShardedGalleryIndex:
         if pending is not None:
             out.append(pending.result())
         return out
+
+
+def verify_exact_topk(index, gallery: torch.Tensor, queries: torch.Tensor, k: int = 10):
+    """Proof that ``index`` (a ``GalleryIndex`` or a ``ShardedGalleryIndex`` over this rank's ``gallery`` rows) returns
+    the exact global top-k for ``queries`` -- four checks that together leave no room for a wrong list:
+
+      (a) every returned global id is re-scored in fp64 by the ONE rank that owns the row and must reproduce the merged
+          dot product (sum over ranks of the owners' re-scores == merged dot64, owner count == 1);
+      (b) the list is in (-dot, +id) order (so ids are unique and ties go to the lowest id);
+      (c) exactly k-1 rows precede the merged k-th entry: every rank counts the entries of its local top-(k+1) list
+          that rank before it, the counts are summed (all-reduce) and must equal k-1 -- a row that beats the merged
+          k-th but is missing from the list (dropped by the merge, or outside a shard's candidates) breaks the count;
+      (d) all ranks hold the same answer (MIN / MAX all-reduce of position-weighted checksums).
+
+    Collectives run on the index's process group (gloo on CPU in tests, RCCL on the GPUs); with no group it checks the
+    single-shard result the same way.  Returns ``("ok" | "FAILED: ...", detail dict)``.  Diagnostic: outside any timed
+    region (bench.py calls it after the clock stops).
+    """
+    sharded = isinstance(index, ShardedGalleryIndex)
+    use_dist = sharded and index.use_dist
+    dist = index.dist if sharded else None
+    group = index.group if sharded else None
+    q2, _ = _as_2d(queries)
+    qd = q2.double()
+    if sharded:
+        _, gidx, d64 = index.search_async(q2, k, 1.0).result(return_dot64=True)
+        offset = index.offset
+        lidx, ld = index.local_topk(q2, k + 1, 1.0)
+    else:
+        _, gidx, d64 = index.search(q2, k, 1.0, return_dot64=True)
+        offset = 0
+        _, lidx, ld = index.search(q2, k + 1, 1.0, return_dot64=True)
+    n_local = gallery.shape[0]
+    Q = q2.shape[0]
+    problems = []
+    # (a) owner re-score
+    mine = (gidx >= offset) & (gidx < offset + n_local)
+    rows = gallery[(gidx - offset).clamp(0, max(n_local - 1, 0)).reshape(-1)].double().reshape(Q, k, -1)
+    re = (rows * qd.unsqueeze(1)).sum(-1)
+    re = torch.where(mine, re, torch.zeros_like(re))
+    owners = mine.to(torch.int32)
+    if use_dist:
+        dist.all_reduce(re, group=group)
+        dist.all_reduce(owners, group=group)
+    if not bool((owners == 1).all()):
+        problems.append("an id is owned by no rank or by several")
+    err = float((re - d64).abs().max()) if re.numel() else 0.0
+    if not err < 1e-12:
+        problems.append(f"re-scored dot differs from the merged dot64 by {err:.3e}")
+    # (b) order and uniqueness
+    if k > 1 and not bool(((d64[:, :-1] > d64[:, 1:]) | ((d64[:, :-1] == d64[:, 1:]) & (gidx[:, :-1] < gidx[:, 1:]))).all()):
+        problems.append("merged list is not in (-dot, +id) order")
+    # (c) exactly k-1 candidates rank before the merged k-th.  Each rank counts the entries of its local top-(k+1) list
+    # that precede the merged k-th entry in (-dot, +id) order; the counts are summed over ranks.  If any row of any
+    # shard beat the merged k-th without being in the merged list, its shard would count it (or, were it outside that
+    # shard's top-(k+1), count k+1 better ones): the sum equals k-1 only for the exact global top-k.
+    lval = lidx >= 0
+    kd, ki = d64[:, k - 1:k], gidx[:, k - 1:k]
+    before = lval & ((ld > kd) | ((ld == kd) & (lidx < ki)))
+    full = gidx[:, k - 1] >= 0                                  # fewer than k rows in total: every candidate is in the list
+    cnt = torch.where(full, before.sum(1), lval.sum(1)).to(torch.int64)
+    if use_dist:
+        dist.all_reduce(cnt, group=group)
+    want = torch.where(full, torch.full_like(cnt, k - 1), (gidx >= 0).sum(1).to(torch.int64))
+    if not bool((cnt == want).all()):
+        problems.append("a candidate that beats the merged k-th is missing from the merged list")
+    # (d) all ranks hold the same answer (position-weighted checksums: a permuted list differs)
+    if use_dist:
+        wq = torch.arange(1, Q + 1, dtype=torch.float64, device=gidx.device).unsqueeze(1)
+        wk = torch.arange(1, k + 1, dtype=torch.float64, device=gidx.device).unsqueeze(0)
+        chk = torch.stack([(gidx.double() * wq * wk).sum(), (d64 * wq * wk).sum()])
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+        if not bool((lo == hi).all()):
+            problems.append("ranks disagree on the merged result")
+    detail = {"rescored_max_abs_err": err, "queries": Q, "k": k, "ranks": index.world if sharded else 1,
+              "checks": "owner re-score == merged dot64; (-dot,+id) order; exactly k-1 candidates precede the merged k-th; ranks agree"}
+    return ("ok" if not problems else "FAILED: " + "; ".join(problems)), detail

@@ -184,6 +184,35 @@ def _sharded_worker(rank, world, port, q):
         ok = ok and bool(np.array_equal(torch.cat([o[0] for o in outs]).numpy(), os_))
         pend = index.search_async(queries, 10, 100.0)          # explicit handle form
         ok = ok and bool(np.array_equal(pend.result()[1].numpy(), oi))
+        # bench.py's post-run proof (search.verify_exact_topk): its all-reduce logic on a real 2-rank group
+        verdict, detail = search.verify_exact_topk(index, local, queries, 10)
+        ok = ok and verdict == "ok" and detail["ranks"] == 2 and detail["rescored_max_abs_err"] < 1e-12
+        v40, _ = search.verify_exact_topk(index, local, queries, 40)     # k beyond what the short shard... still exact
+        ok = ok and v40 == "ok"
+
+        # ... and it must FAIL on a wrong merge.  (i) a merge that drops the best candidate of rank 1's shard:
+        def merge_drops(idx_parts, dot_parts, scale):
+            dot_parts = dot_parts.clone()
+            dot_parts[1, :, 0] = -2.0                          # rank 1's best row is pushed out of every merged list
+            return merge(idx_parts, dot_parts, scale)
+
+        bad = search.ShardedGalleryIndex(local, local_search=local_search, merge=merge_drops)
+        vb, _ = search.verify_exact_topk(bad, local, queries, 10)
+        ok = ok and vb.startswith("FAILED") and "missing from the merged list" in vb
+
+        # (ii) ranks that disagree: rank 1 alone swaps two entries of its merged list
+        def merge_disagrees(idx_parts, dot_parts, scale):
+            sc, ii, dd = merge(idx_parts, dot_parts, scale)
+            if rank == 1:
+                ii = ii.clone(); dd = dd.clone()
+                ii[:, [0, 1]] = ii[:, [1, 0]]
+                dd[:, [0, 1]] = dd[:, [1, 0]]
+            return sc, ii, dd
+
+        bad2 = search.ShardedGalleryIndex(local, local_search=local_search, merge=merge_disagrees)
+        vb2, _ = search.verify_exact_topk(bad2, local, queries, 10)
+        # rank 1's list is out of order, rank 0's is fine: rank 0 learns of it through the checksum all-reduce
+        ok = ok and vb2.startswith("FAILED") and "ranks disagree" in vb2 and (("order" in vb2) == (rank == 1))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
@@ -202,6 +231,22 @@ def test_sharded_search_world2_gloo():
     results = sorted(q.get(timeout=5) for _ in range(2))
     assert results == [(0, True), (1, True)]
     assert all(p.exitcode == 0 for p in procs)
+
+
+def test_bench_starts_its_own_ranks_and_fails_clearly_without_devices():
+    """`python bench.py --gpus N` (no launcher) must start N ranks itself and -- on a node without N GPUs -- exit non-zero
+    with a device message from the ranks, not an argparse-level refusal and not a rendezvous hang.  (Here: no GPU at all.)"""
+    import subprocess
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("this node could actually run two ranks")
+    variants = [["--gpus", "2"]] + ([["--gpus", "1", "--spawn"]] if torch.cuda.device_count() == 0 else [])
+    for argv in variants:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv, "--steps", "1", "--warmup", "0"],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and r.stdout.strip() == ""
+        assert "exited with code" in r.stderr                       # the parent reports which rank went first
+        assert ("needs an MI355X" in r.stderr) or ("device(s)" in r.stderr), r.stderr
 
 
 # ------------------------------------------------------------------ gallery cache formats (host-side)

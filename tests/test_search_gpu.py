@@ -394,7 +394,7 @@ def test_sharded_index_over_rccl(S, oracle, device):
 
 
 def test_c_abi_rccl_allgather_of_topk(S, oracle, device):
-    """The non-Python host's multi-GPU leg (include/mmr.h: mmr_comm_* + mmr_allgather_topk): a one-rank RCCL
+    """The non-Python host's multi-GPU leg (include/mmr.h: mmr_comm_* + mmr_allgather_topk[_packed]): a one-rank RCCL
     communicator built through the C ABI gathers this rank's (global id, fp64 dot) lists and mmr_topk_merge ranks them --
     the same result as the local search.  (More ranks need more GPUs; the exchange itself is rank-count agnostic.)"""
     import ctypes
@@ -421,5 +421,25 @@ def test_c_abi_rccl_allgather_of_topk(S, oracle, device):
         assert np.array_equal((idx - offset).cpu().numpy(), oi) and np.array_equal(d64.cpu().numpy(), od)
         assert np.array_equal(score.cpu().numpy(), os_)
         assert L.mmr_allgather_topk(None, gidx.data_ptr(), ldot.data_ptr(), 12, 10, ip.data_ptr(), dp.data_ptr(), 0) == -22
+        # the packed form -- the sequence include/mmr.h and INTEGRATION.md give, and the exchange the Python index issues:
+        # mmr_cosine_topk_ex (int32 local ids) -> mmr_topk_pack -> ONE all-gather -> mmr_topk_merge_packed
+        gd, qd = gal.to(device), q.to(device)
+        ws = torch.empty(max(256, L.mmr_search_workspace_bytes(9000, 512, 12, 10)), dtype=torch.uint8, device=device)
+        i32 = torch.empty(12, 10, dtype=torch.int32, device=device)
+        sc = torch.empty(12, 10, dtype=torch.float32, device=device)
+        d64l = torch.empty(12, 10, dtype=torch.float64, device=device)
+        st = _lib.stream_ptr(device)
+        _lib.check(L.mmr_cosine_topk_ex(qd.data_ptr(), gd.data_ptr(), _lib.MMR_BF16, 12, 9000, 512, 10, 1.0, 0.0, 0,
+                                        i32.data_ptr(), sc.data_ptr(), d64l.data_ptr(), 0, ws.data_ptr(), ws.numel(), st))
+        packed = torch.empty(12, 10, 2, dtype=torch.int64, device=device)
+        _lib.check(L.mmr_topk_pack(i32.data_ptr(), d64l.data_ptr(), 12, 10, offset, packed.data_ptr(), st))
+        parts = torch.empty(1, 12, 10, 2, dtype=torch.int64, device=device)
+        _lib.check(L.mmr_allgather_topk_packed(comm, packed.data_ptr(), 12, 10, parts.data_ptr(), st))
+        torch.cuda.synchronize(device)
+        assert torch.equal(parts[0], packed)
+        s2, i2, d2 = S.merge_topk_packed(parts, 100.0)
+        assert torch.equal(i2, idx) and torch.equal(d2, d64) and torch.equal(s2, score)
+        assert L.mmr_allgather_topk_packed(None, packed.data_ptr(), 12, 10, parts.data_ptr(), 0) == -22
+        assert L.mmr_allgather_topk_packed(comm, 0, 12, 10, parts.data_ptr(), 0) == -22
     finally:
         L.mmr_comm_destroy(comm)
