@@ -132,20 +132,27 @@ class BertTextEncoder:
         types = None if token_type_ids is None else self._ids_like(token_type_ids, "token_type_ids", (N, T))
         out = torch.empty(N, self.cfg.embed_dim, dtype=self._dtype, device=self.device)
         with torch.cuda.device(self.device):
+            need = self.L.mmr_bert_workspace_bytes(self.handle, min(self.max_batch, N), T) if N else 0
+            if N and (self._ws is None or self._ws.numel() < need):
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            # several slices: OR the per-call status words into one device int (each C call zeroes the word), written
+            # back after the last slice so id_errors() covers the whole call; stream-ordered, no host read
+            acc = torch.zeros(1, dtype=torch.int32, device=self.device) if N > self.max_batch else None
             for s in range(0, N, self.max_batch):
                 n = min(self.max_batch, N - s)
-                need = self.L.mmr_bert_workspace_bytes(self.handle, n, T)
-                if self._ws is None or self._ws.numel() < need:
-                    self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
                 _lib.check(self.L.mmr_bert_forward_masked(
                     self.handle, ids[s:s + n].data_ptr(), _lib.ptr(None if types is None else types[s:s + n]),
                     _lib.ptr(None if mask is None else mask[s:s + n]), n, T, out[s:s + n].data_ptr(),
                     _lib.dtype_code(self._dtype), int(bool(normalize)), int(tap_after), _lib.ptr(tap),
                     self._ws.data_ptr(), self._ws.numel(), _lib.stream_ptr(self.device)))
+                if acc is not None:
+                    acc |= self._ws[:4].view(torch.int32)
+            if acc is not None:
+                self._ws[:4].view(torch.int32).copy_(acc)
         return out
 
     def id_errors(self) -> bool:
-        """True if the last call's (last slice's) kernels saw a token / token-type id out of range (clamped).
+        """True if the last call's kernels -- every slice of it -- saw a token / token-type id out of range (clamped).
         Synchronises; for callers whose ids were produced on the GPU."""
         return self._ws is not None and int(self._ws[:4].view(torch.int32)[0]) != 0
 

@@ -12,9 +12,13 @@ loaders that execute nothing from the file (safetensors, ``torch.load(weights_on
 Pure tensor bookkeeping -- no arithmetic, no GPU.  The name maps are the ones in SURVEY.md
 Appendix A; ``tests/test_checkpoint.py`` checks the HF maps against ``transformers`` itself.
 """
+import io
 import math
 import os
+import pickle
 import re
+import zipfile
+from collections import OrderedDict
 from typing import Dict, Tuple
 
 import torch
@@ -223,22 +227,143 @@ def infer_bert_config(w: Weights, name: str = "checkpoint", ln_eps: float = 1e-1
 
 
 # --------------------------------------------------------------------------------------------- files
+# OpenAI publishes its CLIP checkpoints as TorchScript archives: ``clip.load("ViT-B/32")`` (reference
+# code/search_image.py:327, code/test_clip.py:6) downloads ``ViT-B-32.pt`` into ``~/.cache/clip`` and that is the file a
+# user of the reference has on disk.  ``torch.load(weights_only=True)`` refuses such an archive and ``torch.jit.load``
+# would execute the code stored inside it.  The reader below does neither: a TorchScript archive is a zip holding
+# ``<name>/data.pkl`` (the module tree: nested objects whose attributes are tensors, sub-modules and a few flags) and
+# ``<name>/data/<key>`` (raw storages).  ``data.pkl`` is unpickled with an allow-list -- tensor rebuild calls, storage
+# persistent ids, OrderedDict, and inert placeholder objects for the ``__torch__.*`` module classes; any other global
+# raises -- the ``code/`` directory is never opened, and the state dict is the dotted attribute path of every tensor.
+_STORAGE_DTYPES = {
+    "FloatStorage": torch.float32, "HalfStorage": torch.float16, "BFloat16Storage": torch.bfloat16,
+    "DoubleStorage": torch.float64, "LongStorage": torch.int64, "IntStorage": torch.int32, "ShortStorage": torch.int16,
+    "CharStorage": torch.int8, "ByteStorage": torch.uint8, "BoolStorage": torch.bool,
+}
+
+
+class _ScriptObject:
+    """Inert stand-in for a ``__torch__.*`` class instance: holds the attribute dict pickle's BUILD hands it."""
+
+    def __setstate__(self, state):
+        if not isinstance(state, dict):
+            raise pickle.UnpicklingError("TorchScript module state is not an attribute dict")
+        self.__dict__.update(state)
+
+
+class _StorageType:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+
+def _rebuild_tensor(storage, offset, size, stride, *_ignored):
+    """torch._utils._rebuild_tensor_v2 restated: a strided view over the storage bytes read from the archive."""
+    flat = storage
+    size, stride = tuple(int(x) for x in size), tuple(int(x) for x in stride)
+    need = 1 + sum((n - 1) * st for n, st in zip(size, stride)) if all(n > 0 for n in size) else 0
+    if offset < 0 or any(n < 0 for n in size) or any(st < 0 for st in stride) or offset + need > flat.numel():
+        raise pickle.UnpicklingError("tensor view outside its storage")
+    return torch.as_strided(flat, size, stride, int(offset)).clone()
+
+
+class _ScriptArchiveUnpickler(pickle.Unpickler):
+    def __init__(self, data: bytes, zf, prefix: str):
+        super().__init__(io.BytesIO(data))
+        self._zf, self._prefix, self._storages = zf, prefix, {}
+
+    def find_class(self, module, name):
+        if module == "torch._utils" and name in ("_rebuild_tensor_v2", "_rebuild_tensor"):
+            return _rebuild_tensor
+        if module == "torch._utils" and name == "_rebuild_parameter":
+            return lambda data, requires_grad=False, backward_hooks=None: data
+        if module == "collections" and name == "OrderedDict":
+            return OrderedDict
+        if module == "torch.jit._pickle":
+            # typed-container tags around plain lists / values (Conv2d.stride and the like): restated as identities
+            if name in ("build_intlist", "build_doublelist", "build_boollist", "build_tensorlist"):
+                return lambda data: data
+            if name == "restore_type_tag":
+                return lambda value, type_str=None: value
+        if module == "torch" and name in _STORAGE_DTYPES:
+            return _StorageType(_STORAGE_DTYPES[name])
+        if module == "__torch__" or module.startswith("__torch__."):
+            return type(name, (_ScriptObject,), {})           # a fresh inert class: nothing of the archive's code runs
+        raise pickle.UnpicklingError(f"refusing global {module}.{name}: not part of a tensor-only TorchScript module tree")
+
+    def persistent_load(self, pid):
+        if not (isinstance(pid, tuple) and len(pid) >= 5 and pid[0] == "storage" and isinstance(pid[1], _StorageType)):
+            raise pickle.UnpicklingError(f"unexpected persistent id {pid!r}")
+        _, st, key, _location, numel = pid[:5]
+        key = str(key)
+        if not re.fullmatch(r"[0-9A-Za-z_]+", key):
+            raise pickle.UnpicklingError(f"bad storage key {key!r}")
+        if key not in self._storages:
+            raw = self._zf.read(f"{self._prefix}/data/{key}")
+            t = torch.frombuffer(bytearray(raw), dtype=st.dtype) if raw else torch.empty(0, dtype=st.dtype)
+            if t.numel() < int(numel):
+                raise pickle.UnpicklingError(f"storage {key} holds {t.numel()} elements, {numel} declared")
+            self._storages[key] = t
+        return self._storages[key]
+
+
+def _is_torchscript_archive(path: str) -> bool:
+    if not zipfile.is_zipfile(path):
+        return False
+    with zipfile.ZipFile(path) as zf:
+        names = zf.namelist()
+    return any(n.endswith("/constants.pkl") or "/code/" in n for n in names) and any(n.endswith("/data.pkl") for n in names)
+
+
+def read_torchscript_state_dict(path: str):
+    """State dict of a TorchScript module archive (``torch.jit.save`` / OpenAI's ``ViT-*.pt``) WITHOUT ``torch.jit.load``:
+    nothing stored in the file is executed (see the comment above).  Returns {dotted attribute path: tensor}."""
+    with zipfile.ZipFile(path) as zf:
+        pk = [n for n in zf.namelist() if n.endswith("/data.pkl") and n.count("/") == 1]
+        if len(pk) != 1:
+            raise RuntimeError(f"{path}: expected exactly one <name>/data.pkl, found {pk}")
+        prefix = pk[0].split("/")[0]
+        root = _ScriptArchiveUnpickler(zf.read(pk[0]), zf, prefix).load()
+    if not isinstance(root, _ScriptObject):
+        raise RuntimeError(f"{path}: data.pkl does not hold a module object")
+    sd: Dict[str, torch.Tensor] = {}
+    seen = set()
+
+    def walk(obj, dotted):
+        if id(obj) in seen:                                   # shared sub-modules: first path wins, no cycles
+            return
+        seen.add(id(obj))
+        for k, v in vars(obj).items():
+            if isinstance(v, torch.Tensor):
+                sd[dotted + k] = v
+            elif isinstance(v, _ScriptObject):
+                walk(v, dotted + k + ".")
+
+    walk(root, "")
+    if not sd:
+        raise RuntimeError(f"{path}: the module tree holds no tensors")
+    return sd
+
+
 def read_state_dict(path: str):
-    """Read a checkpoint file WITHOUT executing anything from it: ``.safetensors`` through safetensors,
-    everything else through ``torch.load(weights_only=True)``.  OpenAI's published ``ViT-*.pt`` files are
-    TorchScript archives, which the safe loader refuses; re-save them once where the ``clip`` package is
-    installed: ``torch.save(clip.load(name)[0].state_dict(), "ViT-B-32.state.pt")``."""
+    """Read a checkpoint file WITHOUT executing anything from it: ``.safetensors`` through safetensors, TorchScript
+    archives (OpenAI's published ``ViT-*.pt``, what ``clip.load`` leaves in ``~/.cache/clip``) through
+    :func:`read_torchscript_state_dict`, everything else through ``torch.load(weights_only=True)``."""
     if not os.path.isfile(path):
         raise FileNotFoundError(path)
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
 
         return load_file(path, device="cpu")
+    if _is_torchscript_archive(path):
+        try:
+            return read_torchscript_state_dict(path)
+        except pickle.UnpicklingError as e:
+            raise RuntimeError(f"{path}: TorchScript archive refused: {e}") from e
     try:
         obj = torch.load(path, map_location="cpu", weights_only=True)
-    except Exception as e:  # TorchScript archive / pickled module
+    except Exception as e:  # pickled module / arbitrary objects
         raise RuntimeError(f"{path}: not a plain tensor state dict ({type(e).__name__}: {e}). "
-                           "Only state dicts are loaded (weights_only=True); see read_state_dict.__doc__.") from e
+                           "Only tensors are loaded (weights_only=True / the allow-listed TorchScript reader).") from e
     if isinstance(obj, dict) and "state_dict" in obj and isinstance(obj["state_dict"], dict):
         obj = obj["state_dict"]
     if not isinstance(obj, dict):

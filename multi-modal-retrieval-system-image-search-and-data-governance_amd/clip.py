@@ -275,7 +275,8 @@ class CLIP:
         return text.to(device=self.device, dtype=torch.int32).contiguous()
 
     def text_id_errors(self) -> bool:
-        """True if the LAST encode_text call saw a token id outside [0, vocab) (the kernel clamped it).
+        """True if the LAST encode_text call -- all of its slices when N > max_batch -- saw a token id outside [0, vocab)
+        (the kernel clamped it).
         Synchronises the device; meant for callers that feed ids produced on the GPU."""
         return self.text.status_word() != 0
 
@@ -284,8 +285,18 @@ class CLIP:
         """int [N,77] -> [N,E]; pooled at the EOT token = ``text.argmax(-1)``."""
         ids = self._prep_ids(text)
         with torch.cuda.device(self.device):
-            outs = [self.text.forward(ids[s:s + self.max_batch], self._dtype, normalize)
-                    for s in range(0, ids.shape[0], self.max_batch)]
+            starts = range(0, ids.shape[0], self.max_batch)
+            # every C forward call zeroes the workspace's status word (include/mmr.h): over several slices the words are
+            # OR-ed into one device int and written back after the last slice, so text_id_errors() covers the WHOLE call
+            # (stream-ordered tensor ops, no host read; single-slice calls -- the common case -- launch nothing extra)
+            acc = torch.zeros(1, dtype=torch.int32, device=self.device) if len(starts) > 1 else None
+            outs = []
+            for s in starts:
+                outs.append(self.text.forward(ids[s:s + self.max_batch], self._dtype, normalize))
+                if acc is not None:
+                    acc |= self.text._ws[:4].view(torch.int32)
+            if acc is not None:
+                self.text._ws[:4].view(torch.int32).copy_(acc)
         return outs[0] if len(outs) == 1 else torch.cat(outs) if outs else \
             torch.empty(0, self.cfg.embed_dim, dtype=self._dtype, device=self.device)
 
@@ -389,15 +400,17 @@ class ClipProcessor:
 
 def _find_checkpoint(name: str, download_root: Optional[str]) -> Optional[str]:
     """A checkpoint file for `name`: `name` itself if it is a file, else <download_root>/<ViT-B-32>.{safetensors,state.pt,pt,bin}
-    (the OpenAI package caches "ViT-B/32" as ViT-B-32.pt under download_root)."""
+    (the OpenAI package caches "ViT-B/32" as the TorchScript archive ViT-B-32.pt under download_root, default ~/.cache/clip;
+    checkpoint.read_state_dict reads it with an allow-listed unpickler, without torch.jit.load)."""
     if os.path.isfile(name):
         return name
-    if download_root:
-        stem = name.replace("/", "-").replace("@", "-")
-        for ext in (".safetensors", ".state.pt", ".pt", ".bin"):
-            cand = os.path.join(os.path.expanduser(download_root), stem + ext)
-            if os.path.isfile(cand):
-                return cand
+    # no download_root: the OpenAI package's own default, where a `clip.load(name)` of the reference left its file
+    root = download_root or os.path.join("~", ".cache", "clip")
+    stem = name.replace("/", "-").replace("@", "-")
+    for ext in (".safetensors", ".state.pt", ".pt", ".bin"):
+        cand = os.path.join(os.path.expanduser(root), stem + ext)
+        if os.path.isfile(cand):
+            return cand
     return None
 
 

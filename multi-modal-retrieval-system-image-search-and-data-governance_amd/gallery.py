@@ -81,12 +81,31 @@ def save_feature_cache(path: str, keys: Sequence[str], features: torch.Tensor) -
         pickle.dump(d, f)
 
 
+class _FeatureCacheUnpickler(pickle.Unpickler):
+    """features.pkl is ``{str: np.float32[E]}`` and nothing else: the only globals such a pickle names are numpy's array
+    reconstruction helpers.  Everything else raises -- a cache file cannot run code here."""
+
+    _ALLOWED = {("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+                ("numpy", "ndarray"), ("numpy", "dtype"),
+                ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"feature cache names {module}.{name}: only str keys and numpy arrays are accepted")
+
+
 def load_feature_cache(path: str) -> Tuple[List[str], torch.Tensor]:
     """Read a features.pkl written by ``save_feature_cache`` or by the reference's ``build_cache``
-    (reference code/search_image.py:162-164).  Pickle executes code from the file: only load caches
-    you (or the reference run you trust) wrote."""
+    (reference code/search_image.py:162-164) through an allow-listed unpickler: a dict of str -> numeric numpy array,
+    anything else in the file raises before it can execute."""
     with open(path, "rb") as f:
-        d = pickle.load(f)
+        d = _FeatureCacheUnpickler(f).load()
+    if not isinstance(d, dict):
+        raise pickle.UnpicklingError(f"{path}: expected a dict of features, got {type(d).__name__}")
+    for k, v in d.items():
+        if not isinstance(k, str) or not isinstance(v, np.ndarray) or v.dtype.kind not in "fiu":
+            raise pickle.UnpicklingError(f"{path}: entry {k!r} is not a str -> numeric array pair")
     keys = list(d.keys())
     feats = torch.from_numpy(np.stack([np.asarray(d[k], dtype=np.float32).reshape(-1) for k in keys])) if keys \
         else torch.empty(0, 0)

@@ -139,6 +139,19 @@ def test_bert_masked_long_sequences_and_device_ids(device):
     assert not enc.id_errors()
     with pytest.raises(IndexError):
         enc.logits(bad.cpu())                                              # on the host: checked before the call
+    # N > max_batch runs as several slices over one workspace, each C call zeroing the status word: a bad id in an
+    # EARLIER slice must still be reported, and results of the good rows are untouched
+    enc.max_batch = 4
+    many = torch.randint(1, cfg.vocab, (10, 8), generator=g, dtype=torch.int32).to(device)
+    good = enc.logits(many)
+    assert not enc.id_errors()
+    many_bad = many.clone()
+    many_bad[1, 3] = cfg.vocab + 9                                         # slice 0 of 3
+    out = enc.logits(many_bad)
+    assert enc.id_errors()
+    assert torch.equal(out[[0, 2, 3, 4, 5, 6, 7, 8, 9]], good[[0, 2, 3, 4, 5, 6, 7, 8, 9]])
+    enc.logits(many)
+    assert not enc.id_errors()
 
 
 def test_bert_needs_weights_or_explicit_synthetic(device):

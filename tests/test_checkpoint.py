@@ -128,3 +128,184 @@ def test_load_from_checkpoint_file_matches_weight_dict(tmp_path):
         assert torch.equal(m.encode_image(px), ref)
     with pytest.raises(ValueError, match="does not match"):
         mmr_amd.load("ViT-B/32", device=device, weights=w)
+
+
+# ------------------------------------------------------------------ TorchScript archives (what clip.load leaves on disk)
+class _OaAttn(torch.nn.Module):
+    """nn.MultiheadAttention's parameter names (what the `clip` package's resblocks hold)."""
+
+    def __init__(self, d):
+        super().__init__()
+        self.in_proj_weight = torch.nn.Parameter(torch.zeros(3 * d, d))
+        self.in_proj_bias = torch.nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = torch.nn.Linear(d, d)
+
+    def forward(self, x):
+        return self.out_proj(x)
+
+
+class _OaBlock(torch.nn.Module):
+    def __init__(self, d, m):
+        super().__init__()
+        from collections import OrderedDict
+        self.attn = _OaAttn(d)
+        self.ln_1 = torch.nn.LayerNorm(d)
+        self.mlp = torch.nn.Sequential(OrderedDict([("c_fc", torch.nn.Linear(d, m)), ("gelu", torch.nn.GELU()),
+                                                    ("c_proj", torch.nn.Linear(m, d))]))
+        self.ln_2 = torch.nn.LayerNorm(d)
+
+    def forward(self, x):
+        return x + self.mlp(self.ln_2(x + self.attn(self.ln_1(x))))
+
+
+class _OaTransformer(torch.nn.Module):
+    def __init__(self, d, m, layers):
+        super().__init__()
+        self.resblocks = torch.nn.Sequential(*[_OaBlock(d, m) for _ in range(layers)])
+
+    def forward(self, x):
+        return self.resblocks(x)
+
+
+class _OaVisual(torch.nn.Module):
+    def __init__(self, t, E):
+        super().__init__()
+        d = t.width
+        self.conv1 = torch.nn.Conv2d(3, d, t.patch, t.patch, bias=False)
+        self.class_embedding = torch.nn.Parameter(torch.zeros(d))
+        self.positional_embedding = torch.nn.Parameter(torch.zeros(t.tokens, d))
+        self.ln_pre = torch.nn.LayerNorm(d)
+        self.transformer = _OaTransformer(d, t.mlp, t.layers)
+        self.ln_post = torch.nn.LayerNorm(d)
+        self.proj = torch.nn.Parameter(torch.zeros(d, E))
+
+    def forward(self, x):
+        return self.ln_post(self.transformer(self.ln_pre(x))) @ self.proj
+
+
+class _OaClip(torch.nn.Module):
+    """Module tree with the tensor names of the `clip` package's CLIP class; forward is irrelevant (never run)."""
+
+    def __init__(self, ccfg):
+        super().__init__()
+        t = ccfg.text
+        self.visual = _OaVisual(ccfg.vision, ccfg.embed_dim)
+        self.transformer = _OaTransformer(t.width, t.mlp, t.layers)
+        self.token_embedding = torch.nn.Embedding(t.vocab, t.width)
+        self.positional_embedding = torch.nn.Parameter(torch.zeros(t.tokens, t.width))
+        self.ln_final = torch.nn.LayerNorm(t.width)
+        self.text_projection = torch.nn.Parameter(torch.zeros(t.width, ccfg.embed_dim))
+        self.logit_scale = torch.nn.Parameter(torch.ones([]))
+
+    def forward(self, x):
+        return self.ln_final(self.transformer(x)) @ self.text_projection * self.logit_scale
+
+
+def _write_torchscript_clip(path, ccfg, w, half=True):
+    m = _OaClip(ccfg)
+    sd = checkpoint.to_openai_state_dict(w)
+    missing, unexpected = m.load_state_dict(sd, strict=True)
+    assert not missing and not unexpected
+    if half:
+        m = m.half()                                   # clip.load's CUDA archives hold fp16 weights
+    torch.jit.save(torch.jit.script(m), str(path))
+
+
+def test_torchscript_archive_is_read_without_running_it(tmp_path):
+    """`clip.load("ViT-B/32")` caches OpenAI's TorchScript `ViT-B-32.pt`; that is the file a user of the
+    reference has.  It must load through the allow-listed reader (no torch.jit.load, nothing executed) and convert."""
+    ccfg = mmr_amd.get_config("tiny-test")
+    w = weights.make_clip_weights(ccfg, seed=8)
+    pt = tmp_path / "tiny-test.pt"
+    _write_torchscript_clip(pt, ccfg, w)
+    assert checkpoint._is_torchscript_archive(str(pt))
+    with pytest.raises(Exception):
+        torch.load(str(pt), weights_only=True)          # the stock safe loader refuses the archive
+    sd = checkpoint.read_state_dict(str(pt))
+    ref = torch.jit.load(str(pt)).state_dict()          # test-only cross-check on an archive this test wrote itself
+    assert set(sd) == set(ref) and all(torch.equal(sd[k], ref[k]) for k in ref)
+    assert sd["visual.conv1.weight"].dtype == torch.float16
+    cfg, conv = checkpoint.load_clip_checkpoint(str(pt), "tiny-test")
+    assert (cfg.vision, cfg.text) == (ccfg.vision, ccfg.text) and set(conv) == set(w)
+    for k in w:
+        assert torch.equal(conv[k], w[k].half().float()), k
+    # a plain state-dict zip is not mistaken for an archive
+    plain = tmp_path / "plain.pt"
+    torch.save(checkpoint.to_openai_state_dict(w), str(plain))
+    assert not checkpoint._is_torchscript_archive(str(plain))
+
+
+def test_torchscript_reader_refuses_anything_but_tensors(tmp_path):
+    """A data.pkl that names any global outside the allow-list (here: os.system via REDUCE) raises before anything runs;
+    so do a storage view that leaves its storage and a path-escaping storage key."""
+    import io
+    import pickle
+    import zipfile
+
+    class Evil:
+        def __reduce__(self):
+            import os as _os
+            return (_os.system, ("echo pwned > /tmp/mmr_pwned",))
+
+    def archive(name, data_pkl, extra=()):
+        p = tmp_path / name
+        with zipfile.ZipFile(p, "w") as zf:
+            zf.writestr("m/data.pkl", data_pkl)
+            zf.writestr("m/constants.pkl", pickle.dumps(()))
+            zf.writestr("m/code/__torch__.py", "")
+            zf.writestr("m/version", "3\n")
+            for k, v in extra:
+                zf.writestr(k, v)
+        return str(p)
+
+    if os.path.exists("/tmp/mmr_pwned"):
+        os.remove("/tmp/mmr_pwned")
+    with pytest.raises(RuntimeError, match="refused"):
+        checkpoint.read_state_dict(archive("evil.pt", pickle.dumps(Evil(), protocol=2)))
+    assert not os.path.exists("/tmp/mmr_pwned")
+
+    # hand-assembled pickles: module object {"w": tensor view}
+    def module_with(pid_key, numel, offset, size, stride, storage_bytes):
+        P = pickle
+        b = io.BytesIO()
+        b.write(P.PROTO + b"\x02")
+        b.write(P.GLOBAL + b"__torch__\nM\n" + P.EMPTY_TUPLE + P.NEWOBJ + P.EMPTY_DICT + P.MARK)
+        b.write(P.BINUNICODE + len(b"w").to_bytes(4, "little") + b"w")
+        b.write(P.GLOBAL + b"torch._utils\n_rebuild_tensor_v2\n" + P.MARK)
+        b.write(P.MARK + P.BINUNICODE + (7).to_bytes(4, "little") + b"storage" + P.GLOBAL + b"torch\nFloatStorage\n")
+        kb = pid_key.encode()
+        b.write(P.BINUNICODE + len(kb).to_bytes(4, "little") + kb + P.BINUNICODE + (3).to_bytes(4, "little") + b"cpu")
+        b.write(P.BININT + numel.to_bytes(4, "little", signed=True) + P.TUPLE + P.BINPERSID)
+        b.write(P.BININT + offset.to_bytes(4, "little", signed=True))
+        b.write(P.MARK + b"".join(P.BININT + s.to_bytes(4, "little", signed=True) for s in size) + P.TUPLE)
+        b.write(P.MARK + b"".join(P.BININT + s.to_bytes(4, "little", signed=True) for s in stride) + P.TUPLE)
+        b.write(P.NEWFALSE + P.GLOBAL + b"collections\nOrderedDict\n" + P.EMPTY_TUPLE + P.REDUCE + P.TUPLE + P.REDUCE)
+        b.write(P.SETITEMS + P.BUILD + P.STOP)
+        return b.getvalue(), storage_bytes
+
+    good, raw = module_with("0", 6, 0, (2, 3), (3, 1), torch.arange(6, dtype=torch.float32).numpy().tobytes())
+    sd = checkpoint.read_state_dict(archive("good.pt", good, [("m/data/0", raw)]))
+    assert torch.equal(sd["w"], torch.arange(6, dtype=torch.float32).view(2, 3))
+    oob, raw = module_with("0", 6, 2, (2, 3), (3, 1), raw)                      # view runs past the storage
+    with pytest.raises(RuntimeError, match="outside its storage"):
+        checkpoint.read_state_dict(archive("oob.pt", oob, [("m/data/0", raw)]))
+    esc, raw = module_with("../../etc/passwd", 6, 0, (2, 3), (3, 1), raw)       # storage key is not a plain token
+    with pytest.raises(RuntimeError, match="bad storage key"):
+        checkpoint.read_state_dict(archive("esc.pt", esc, [("m/data/0", raw)]))
+
+
+@pytest.mark.gpu
+def test_clip_load_reads_the_cached_torchscript_file(tmp_path):
+    """`clip.load("ViT-B/32", download_root=d)` with d/ViT-B-32.pt in TorchScript layout (reference
+    code/search_image.py:327) -- here at the tiny geometry, through the same code path."""
+    device = torch.device("cuda:0")
+    ccfg = mmr_amd.get_config("tiny-test")
+    w = weights.make_clip_weights(ccfg, seed=8)
+    _write_torchscript_clip(tmp_path / "tiny-test.pt", ccfg, w, half=False)
+    px = synth.synth_images(3, ccfg.vision.image_size, seed=1).to(device)
+    ids = synth.synth_token_ids(2, ccfg.text.tokens, ccfg.text.vocab, seed=2).to(device)
+    ref_model, _ = mmr_amd.load("tiny-test", device=device, weights=w)
+    m, _ = mmr_amd.load("tiny-test", device=device, download_root=str(tmp_path))
+    assert not m.synthetic_weights
+    assert torch.equal(m.encode_image(px), ref_model.encode_image(px))
+    assert torch.equal(m.encode_text(ids), ref_model.encode_text(ids))

@@ -539,6 +539,18 @@ def test_no_host_sync_surface_details(device):
     assert model.text_id_errors() and torch.isfinite(out).all()
     assert torch.equal(out[0], ok[0]) and torch.equal(out[2], ok[2])
     assert torch.equal(model.encode_text(ids.to(device)), ok) and not model.text_id_errors()
+    # N > max_batch: several slices over one workspace, each C call zeroing the status word -- a bad id in slice 0 of 3
+    # must still be flagged by the call as a whole, also when the ids are already on the GPU
+    model.max_batch = 2
+    five = synth.synth_token_ids(5, 77, V, seed=3)
+    good5 = model.encode_text(five.to(device))
+    assert not model.text_id_errors()
+    bad5 = five.clone()
+    bad5[0, 7] = V + 1
+    out5 = model.encode_text(bad5.to(device))
+    assert model.text_id_errors() and torch.equal(out5[1:], good5[1:])
+    assert torch.equal(model.encode_text(five.to(device)), good5) and not model.text_id_errors()
+    model.max_batch = 512
     assert abs(model._logit_scale_exp - float(model.logit_scale.exp())) < 1e-4
     # preprocess dtype follows the model (fp32 like the reference's preprocess; bf16 after .bfloat16()), and an explicit
     # request wins; bf16 pixels give bit-identical features (the encoder rounds pixels to bf16 on the way in)

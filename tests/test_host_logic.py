@@ -270,6 +270,24 @@ def test_feature_cache_formats_round_trip(tmp_path):
     assert k3 == keys and torch.equal(f3, feats.float())
     with pytest.raises(ValueError):
         gallery.save_feature_cache(str(p), keys[:3], feats)
+    # the loader is allow-listed: a cache file that names anything but numpy's array helpers raises before it runs
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /tmp/mmr_cache_pwned",))
+
+    if os.path.exists("/tmp/mmr_cache_pwned"):
+        os.remove("/tmp/mmr_cache_pwned")
+    pickle.dump({"a.jpg": Evil()}, open(tmp_path / "evil.pkl", "wb"))
+    with pytest.raises(pickle.UnpicklingError):
+        gallery.load_feature_cache(str(tmp_path / "evil.pkl"))
+    assert not os.path.exists("/tmp/mmr_cache_pwned")
+    pickle.dump({"a.jpg": np.array(["x"], dtype=object)}, open(tmp_path / "obj.pkl", "wb"))
+    with pytest.raises(pickle.UnpicklingError):
+        gallery.load_feature_cache(str(tmp_path / "obj.pkl"))
+    pickle.dump([1, 2, 3], open(tmp_path / "list.pkl", "wb"))
+    with pytest.raises(pickle.UnpicklingError):
+        gallery.load_feature_cache(str(tmp_path / "list.pkl"))
     labels = torch.arange(7)
     gallery.save_split_features(str(tmp_path / "c"), "val", feats.float(), labels)
     f4, l4 = gallery.load_split_features(str(tmp_path / "c"), "val")
