@@ -145,6 +145,8 @@ class _Tower:
         if B == 0:
             return out
         ws = self.workspace(B)
+        if inp.data_ptr() & 15:            # a slice of a larger batch can start off the 16-byte grid the kernels load on
+            inp = inp.clone()
         in_code = _lib.dtype_code(inp.dtype) if self.cfg.kind == "vision" else _lib.MMR_F32
         _lib.check(self.L.mmr_tower_forward(self.handle, inp.data_ptr(), in_code, B, out.data_ptr(),
                                             _lib.dtype_code(out_dtype), int(bool(normalize)), int(tap_after),
