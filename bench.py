@@ -21,6 +21,9 @@ Workloads (--config; names follow SURVEY.md section 8d; per RANK, weak scaling -
   cfg3  BASELINE configs[2]: CLIP text tower bf16 on 256 prompts, their features are the queries over 1M x 512 rows
   cfg4  BASELINE configs[3]: search only, 1.25M x 512 rows per rank (8 ranks = the 10M gallery), 256 queries
   cfg5  BASELINE configs[4]: ViT-L/14@336 bf16 encode of 128 images per rank + top-10 of 128 queries over 1M x 768 rows
+  build the reference's gallery loop from RAW images (code/search_image.py:142-165): 256 uint8 480x640 images per step ->
+        Pillow-exact preprocess -> ViT-B/32 encode -> normalise -> gallery rows, preprocess overlapped with the previous
+        batch's encode; reported beside the serial schedule and encode-only (no search leg)
 One STEP, per rank (inputs already resident in HBM): the config's encode leg (none for cfg4), then the search leg:
 local top-10 over this rank's shard; for N > 1 ONE RCCL all-gather (all_gather_into_tensor, async) of the packed
 per-shard top-10 and an exact merge.  With N > 1 the steps are software-pipelined: step i's all-gather is in
@@ -59,6 +62,9 @@ CONFIGS = {
     "cfg3": dict(model="ViT-B/32", encode="text", batch=256, rows=1_000_000, queries=256, baseline="configs[2]"),
     "cfg4": dict(model="ViT-B/32", encode="none", batch=0, rows=1_250_000, queries=256, baseline="configs[3]"),
     "cfg5": dict(model="ViT-L/14@336px", encode="image", batch=128, rows=1_000_000, queries=128, baseline="configs[4]"),
+    # the reference's gallery loop end to end (code/search_image.py:142-165): raw uint8 VGA images -> preprocess -> encode ->
+    # normalise -> rows of a preallocated gallery; preprocess of batch i+1 overlapped with the encode of batch i
+    "build": dict(model="ViT-B/32", encode="build", batch=256, rows=0, queries=0, baseline="configs[1] encode leg, from raw images"),
 }
 
 
@@ -183,6 +189,103 @@ def spawn_ranks(n, argv):
     raise SystemExit(rc if rc >= 0 else 1)
 
 
+def build_leg(args, C, custom, dev, rank, world, use_dist, dist):
+    """--config build: K steps of  uint8 [B,480,640,3] (resident) -> Pillow-exact preprocess -> ViT encode -> L2-normalise ->
+    rows of a preallocated gallery, the preprocess of batch i+1 on a side stream under the encode of batch i
+    (gallery.build_gallery_overlapped).  Timed beside it in the same process: the same K batches with the two stages back
+    to back on one stream (serial), and encode alone on already-preprocessed pixels.  The overlapped gallery must equal the
+    serial one bit for bit, and the serial one the plain per-batch preprocess_batch + encode_image."""
+    import mmr_amd
+    from mmr_amd import _lib, gallery, preprocess
+
+    B, K, Wm = C["batch"], args.steps, args.warmup
+    H, W = 480, 640
+    model, _ = mmr_amd.load(C["model"], device=dev, weights="synthetic")
+    model.bfloat16()
+    E, S = model.cfg.embed_dim, model.input_resolution
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    raws = [torch.randint(0, 256, (B, H, W, 3), dtype=torch.uint8, device=dev, generator=g) for _ in range(2)]
+
+    def batches(n):
+        return (raws[i & 1] for i in range(n))
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def timed(fn):
+        fence()
+        t0 = time.perf_counter()
+        r = fn()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), r
+
+    gal = torch.empty(K * B, E, dtype=torch.bfloat16, device=dev)
+    gallery.build_gallery_overlapped(model, batches(Wm + 2), total=(Wm + 2) * B)                 # warm-up (both slots)
+    t_ovl, g_ovl = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal))
+    g_ovl = g_ovl.clone()
+    t_ser, g_ser = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal, overlap=False))
+    g_ser = g_ser.clone()
+    px = [preprocess.preprocess_batch(list(r), S, out_dtype=torch.bfloat16) for r in raws]
+
+    def enc_only():
+        for i in range(K):
+            model.encode_image(px[i & 1], normalize=True, out=gal[i * B:(i + 1) * B])
+        return gal
+
+    enc_only()
+    t_enc, g_enc = timed(enc_only)
+    pre = preprocess.UniformBatchPreprocessor(B, H, W, S, device=dev, slots=1)
+
+    def pre_only():
+        for i in range(K):
+            pre(raws[i & 1], 0)
+
+    pre_only()
+    t_pre, _ = timed(pre_only)
+    same_ovl = bool(torch.equal(g_ovl, g_ser))
+    same_ref = bool(torch.equal(g_ser[:2 * B], g_enc[:2 * B])) and bool(torch.equal(g_ser, g_enc))
+    ok = same_ovl and same_ref and bool(torch.isfinite(g_ovl.float()).all())
+    gflops, n_gemm = gemm_flops_per_forward(model.cfg.vision, B)
+    # roofline of the dominant kernel (the bf16 GEMMs), launch durations from a second, instrumented pass
+    _lib.prof_enable(True, max(4096, 300 * K))
+    gallery.build_gallery_overlapped(model, batches(K), gallery=gal)
+    torch.cuda.synchronize(dev)
+    _lib.prof_enable(False)
+    prof = _lib.prof_read()
+    gemm_ms, gemm_n = prof["gemm"]
+    gemm_tflops = gflops * (gemm_n / n_gemm) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    imgs = world * K * B
+    line = {
+        "metric": METRIC, "value": round(imgs / t_ovl, 1), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(t_ovl / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": (f"gallery build from raw images: {B} uint8 {H}x{W}x3 images/GPU per step (resident) -> bicubic "
+                                f"resize + centre crop + normalise ({S}x{S}, Pillow-exact) -> {C['model']} bf16 encode -> "
+                                f"L2-normalise -> rows of a preallocated [{K * B},{E}] bf16 gallery (BASELINE {C['baseline']}"
+                                f"{'; CUSTOM ' + ' '.join(custom) if custom else ''})"),
+                   "name": "build", "encode_batch_per_gpu": B, "image_hw": [H, W],
+                   "parallelism": f"dp{world} (no collective)" if use_dist else "single GPU",
+                   "schedule": "preprocess of batch i+1 on a side stream under the encode of batch i",
+                   "weights": "seeded random init (no checkpoint reachable offline)"},
+        "verify": "ok" if ok else "FAILED",
+        "verify_detail": {"overlapped_equals_serial_bitwise": same_ovl, "serial_equals_preprocess_batch_then_encode_bitwise": same_ref},
+        "build_images_per_s": round(imgs / t_ovl, 1), "build_serial_images_per_s": round(imgs / t_ser, 1),
+        "encode_only_images_per_s": round(imgs / t_enc, 1), "preprocess_only_images_per_s": round(imgs / t_pre, 1),
+        "build_over_encode_only": round(t_enc / t_ovl, 4), "serial_over_encode_only": round(t_enc / t_ser, 4),
+        "roofline": {"kernel": "bf16 MFMA GEMMs of the image tower (all epilogues)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
+                     "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                     "avg_launch_us": round(gemm_ms / gemm_n * 1e3, 2) if gemm_n else None, "launches": gemm_n,
+                     "measured": "HIP event pairs around each launch, second pass (with the preprocess running beside it)"},
+    }
+    return line, ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -249,6 +352,18 @@ def main():
 
     import mmr_amd
     from mmr_amd import _lib, search, synth
+
+    if ENC == "build":
+        line, ok = build_leg(args, C, custom, dev, rank, world, use_dist, dist)
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+        if use_dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        if not ok:
+            raise SystemExit("bench build leg: verification failed")
+        return
 
     model, _ = mmr_amd.load(MODEL, device=dev, weights="synthetic")     # no checkpoint is reachable offline
     model.bfloat16()

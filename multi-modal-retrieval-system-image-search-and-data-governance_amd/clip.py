@@ -139,9 +139,13 @@ class _Tower:
         return 0 if self._ws is None else int(self._ws[:4].view(torch.int32)[0])
 
     def forward(self, inp: torch.Tensor, out_dtype: torch.dtype, normalize: bool, tap_after: int = -1,
-                tap: Optional[torch.Tensor] = None) -> torch.Tensor:
+                tap: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         B = inp.shape[0]
-        out = torch.empty(B, self.cfg.embed_dim, dtype=out_dtype, device=self.device)
+        if out is None:
+            out = torch.empty(B, self.cfg.embed_dim, dtype=out_dtype, device=self.device)
+        elif (tuple(out.shape) != (B, self.cfg.embed_dim) or out.dtype != out_dtype or not out.is_contiguous()
+              or out.device != self.device):
+            raise ValueError(f"out must be a contiguous {out_dtype} [{B},{self.cfg.embed_dim}] tensor on {self.device}")
         if B == 0:
             return out
         ws = self.workspace(B)
@@ -249,12 +253,18 @@ class CLIP:
         return image.to(self.device).contiguous()
 
     @torch.no_grad()
-    def encode_image(self, image: torch.Tensor, normalize: bool = False) -> torch.Tensor:
-        """[B,3,S,S] -> [B,E] in ``self.dtype``; a fresh, writable tensor (callers do ``/=`` on it)."""
+    def encode_image(self, image: torch.Tensor, normalize: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[B,3,S,S] -> [B,E] in ``self.dtype``; a fresh, writable tensor (callers do ``/=`` on it).  ``out``: write the
+        rows into this preallocated [B,E] tensor instead (a slice of a gallery being built) and return it."""
         px = self._prep_pixels(image)
+        if out is not None and tuple(out.shape) != (px.shape[0], self.cfg.embed_dim):
+            raise ValueError(f"out must be [{px.shape[0]},{self.cfg.embed_dim}], got {tuple(out.shape)}")
         with torch.cuda.device(self.device):
-            outs = [self.visual.forward(px[s:s + self.max_batch], self._dtype, normalize)
+            outs = [self.visual.forward(px[s:s + self.max_batch], self._dtype, normalize,
+                                        out=None if out is None else out[s:s + self.max_batch])
                     for s in range(0, px.shape[0], self.max_batch)]
+        if out is not None:
+            return out
         return outs[0] if len(outs) == 1 else torch.cat(outs) if outs else \
             torch.empty(0, self.cfg.embed_dim, dtype=self._dtype, device=self.device)
 

@@ -879,6 +879,21 @@ __global__ __launch_bounds__(GEMM2_THREADS, 2) void gemm256_bf16_kernel(
     gemm256_tile<EPI, NIW, PATCH>(A, W, M, N, K, bias, out, aux, m0, n0, smem);
 }
 
+static int device_cus()
+{
+    // CUs of the current device (256 on MI355X): the persistent launches run one workgroup per CU and the tile-shape choice
+    // counts rounds over the CUs -- taken from the device, not assumed
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        hipDeviceProp_t prop;
+        cached = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 static int tile_group_panels(int gn)
 {
     // panels per tile-order group.  Round 1 sized it so that one XCD's concurrent set (32 CUs) is near-square (6 .. 8
@@ -953,7 +968,8 @@ static int launch_gemm256_persist(const bf16_t *A, const bf16_t *W, int M, int N
                                           hipFuncAttributeMaxDynamicSharedMemorySize, GEMM2P_LDS));
     }
     const int panels = M / BM2, gn = N / 256;
-    const int grid = panels * gn < 256 ? panels * gn : 256;
+    const int cus = device_cus();
+    const int grid = panels * gn < cus ? panels * gn : cus;
     PersistPlan plan{};
     plan.ph = persist_half_panels(panels, gn, grid);
     plan.nfull = (panels - plan.ph) * gn;
@@ -1162,7 +1178,7 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
     static const int force = getenv("MMR_GEMM_TILE") ? atoi(getenv("MMR_GEMM_TILE")) : 0;   // 128 / 192 / 256: A/B aid
     // Tile choice.  The 256-row kernels run one workgroup per CU: they need enough tiles to occupy the chip, and
     // among the two widths the cheaper is the one with fewer (rounds over 256 CUs) x (tile width).
-    const int cus = 256;
+    const int cus = device_cus();
     auto cost = [&](int bn) -> long long {
         if (M % BM2 || N % bn) return -1;
         const long long tiles = (long long)(M / BM2) * (N / bn);
@@ -1197,7 +1213,7 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
     // multi-round launches with a bf16 epilogue (qkv, fc1): persistent workgroups over a full + half tile list
     // (gemm256_persist_kernel); MMR_GEMM_PERSIST=0 falls back to one workgroup per tile (A/B aid)
     static const int persist = getenv("MMR_GEMM_PERSIST") ? atoi(getenv("MMR_GEMM_PERSIST")) : 1;
-    if (persist && tile == 256 && (long long)(M / BM2) * (N / 256) > 256) {
+    if (persist && tile == 256 && (long long)(M / BM2) * (N / 256) > cus) {
         switch (epi) {
             case EPI_BIAS_BF16: return launch_gemm256_persist<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
             case EPI_BIAS_GELU_BF16: return launch_gemm256_persist<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);

@@ -56,6 +56,72 @@ def encode_gallery(model, batches: Iterable, normalize: bool = True, out_dtype: 
     return out
 
 
+@torch.no_grad()
+def build_gallery_overlapped(model, raw_batches: Iterable[torch.Tensor], total: Optional[int] = None,
+                             out_dtype: torch.dtype = torch.bfloat16, overlap: bool = True,
+                             gallery: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The reference's gallery loop ``preprocess -> encode_image -> normalise -> keep the row``
+    (code/search_image.py:153-158) over batches of raw uint8 images [b,H,W,3] that already sit on the GPU, with the two
+    device stages OVERLAPPED: batch i+1 is preprocessed on a side stream (Pillow-exact bicubic resize + crop + normalise,
+    csrc/preprocess.hip) while batch i goes through the towers on the caller's stream, and the L2-normalised rows land
+    directly in a preallocated gallery [N,E] (``normalize=1`` fused into the encoder's last kernel; no torch.cat).
+    ``overlap=False`` runs the same launches back to back on one stream -- the results are bit-identical either way
+    (tested); only the schedule differs.  All batches must share one image size (``UniformBatchPreprocessor``).
+    Returns the gallery (rows in arrival order)."""
+    from .preprocess import UniformBatchPreprocessor
+
+    it = iter(raw_batches)
+    first = next(it, None)
+    dev = model.device
+    E = model.cfg.embed_dim
+    if first is None:
+        return torch.empty(0, E, dtype=out_dtype, device=dev) if gallery is None else gallery[:0]
+    B, H, W = int(first.shape[0]), int(first.shape[1]), int(first.shape[2])
+    B = max(B, 1)
+    if gallery is None:
+        if total is None:
+            raise ValueError("pass total= (rows to allocate) or a preallocated gallery")
+        gallery = torch.empty(int(total), E, dtype=out_dtype, device=dev)
+    prev_dtype = model.dtype
+    model.to(gallery.dtype)
+    S = model.input_resolution
+    pre = UniformBatchPreprocessor(B, H, W, S, out_dtype=torch.bfloat16, device=dev, slots=2)
+    main = torch.cuda.current_stream(dev)
+    side = torch.cuda.Stream(dev) if overlap else main
+    ready = [torch.cuda.Event(), torch.cuda.Event()]          # slot's pixels written (side -> main)
+    row = 0
+    try:
+        def launch_pre(raw, slot):
+            # Called BEFORE the current batch's encode is enqueued: waiting for everything the main stream holds at this
+            # point means (a) the raw images, if the caller produced them on the main stream, are complete and (b) the
+            # encode two batches back -- the last reader of this slot's pixel buffer -- has finished; the current batch's
+            # encode is enqueued afterwards and runs concurrently with this preprocess.
+            if overlap:
+                side.wait_stream(main)
+                raw.record_stream(side)
+            with torch.cuda.stream(side):
+                px = pre(raw, slot)
+                ready[slot].record(side)
+            return px
+
+        cur, i = first, 0
+        px = launch_pre(cur, 0)
+        while cur is not None:
+            nxt = next(it, None)
+            px_next = launch_pre(nxt, (i + 1) & 1) if nxt is not None else None       # flies under this batch's encode
+            if overlap:
+                main.wait_event(ready[i & 1])
+            b = int(cur.shape[0])
+            if row + b > gallery.shape[0]:
+                raise ValueError(f"gallery of {gallery.shape[0]} rows is too small")
+            model.encode_image(px, normalize=True, out=gallery[row:row + b])
+            row += b
+            cur, px, i = nxt, px_next, i + 1
+    finally:
+        model.to(prev_dtype)
+    return gallery[:row]
+
+
 def batched(items: Sequence, load: Callable, batch_size: int = 256):
     """Yield stacked [b,3,S,S] tensors from ``load(item)`` results (one preprocessed image each)."""
     buf = []

@@ -178,3 +178,58 @@ def preprocess_batch(images: Sequence[torch.Tensor], n_px: int = 224, out_dtype:
     # descriptors, tables and images must outlive the launch: tie them to the output's lifetime
     out._mmr_keepalive = (desc_d, tmp, imgs)
     return out
+
+
+class UniformBatchPreprocessor:
+    """``preprocess`` for batches of SAME-SIZE images held as one uint8 tensor [B,H,W,3] on the GPU (a decoded video
+    frame stack, a dataset stored at one resolution): the per-image descriptors differ only in two pointers, so they are
+    built with three numpy array ops instead of a Python loop, staged in PINNED host memory and uploaded asynchronously --
+    the call returns at once and can run on a side stream under the previous batch's ``encode_image``
+    (``gallery.build_gallery_overlapped``).  Same kernels (``mmr_preprocess_batch``), same bytes as
+    ``preprocess_image`` / Pillow.  One instance owns ``slots`` sets of buffers (descriptors, vertical-pass scratch,
+    output pixels): slot ``i`` may be reused once the consumer of its previous output has finished."""
+
+    def __init__(self, batch: int, height: int, width: int, n_px: int = 224, out_dtype: torch.dtype = torch.bfloat16,
+                 device="cuda", slots: int = 2, mean: Sequence[float] = CLIP_MEAN, std: Sequence[float] = CLIP_STD):
+        self.B, self.H, self.W, self.S = int(batch), int(height), int(width), int(n_px)
+        self.device = torch.device(device)
+        self.mean, self.std, self.out_dtype = tuple(mean), tuple(std), out_dtype
+        self.t = _device_tables(self.H, self.W, self.S, self.device)
+        self.rows = self.t["row1"] - self.t["row0"]
+        self.tmp_stride = self.rows * self.S * 3
+        self.slots = []
+        for _ in range(slots):
+            self.slots.append(dict(
+                desc_h=torch.zeros(self.B, 9, dtype=torch.int64).pin_memory(),
+                desc_d=torch.zeros(self.B, 9, dtype=torch.int64, device=self.device),
+                tmp=torch.empty(self.B * self.tmp_stride + 16, dtype=torch.uint8, device=self.device),
+                out=torch.empty(self.B, 3, self.S, self.S, dtype=out_dtype, device=self.device)))
+        ints = np.array([self.H, self.W, self.t["row0"], self.rows, self.t["hk"], self.t["vk"]], dtype=np.int32).view(np.int64)
+        for sl in self.slots:                                  # everything but the image pointers is fixed per slot
+            d = sl["desc_h"].numpy()
+            d[:, 1], d[:, 2] = self.t["hb"].data_ptr(), self.t["hc"].data_ptr()
+            d[:, 3], d[:, 4] = self.t["vb"].data_ptr(), self.t["vc"].data_ptr()
+            d[:, 5] = sl["tmp"].data_ptr() + np.arange(self.B, dtype=np.int64) * self.tmp_stride
+            d[:, 6:9] = ints
+
+    @torch.no_grad()
+    def __call__(self, images_u8: torch.Tensor, slot: int = 0) -> torch.Tensor:
+        """[b,H,W,3] uint8 (b <= batch) -> the slot's pixel buffer [b,3,S,S]; enqueued on the CURRENT stream."""
+        if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or tuple(images_u8.shape[1:]) != (self.H, self.W, 3):
+            raise ValueError(f"expected uint8 [b,{self.H},{self.W},3], got {images_u8.dtype} {tuple(images_u8.shape)}")
+        if not images_u8.is_cuda:
+            raise RuntimeError("images must live on the GPU (there is no CPU path)")
+        b = int(images_u8.shape[0])
+        if not 1 <= b <= self.B:
+            raise ValueError(f"batch {b} outside [1,{self.B}]")
+        images_u8 = images_u8.contiguous()
+        sl = self.slots[slot]
+        sl["desc_h"].numpy()[:b, 0] = images_u8.data_ptr() + np.arange(b, dtype=np.int64) * (self.H * self.W * 3)
+        sl["desc_d"][:b].copy_(sl["desc_h"][:b], non_blocking=True)
+        out = sl["out"][:b]
+        L = _lib.lib()
+        _lib.check(L.mmr_preprocess_batch(sl["desc_d"].data_ptr(), b, self.S, int(self.rows), float(self.mean[0]),
+                                          float(self.mean[1]), float(self.mean[2]), float(self.std[0]), float(self.std[1]),
+                                          float(self.std[2]), out.data_ptr(), _lib.dtype_code(self.out_dtype),
+                                          _lib.stream_ptr(self.device)))
+        return out

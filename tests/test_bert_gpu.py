@@ -12,6 +12,9 @@ from mmr_amd.config import get_bert_config
 
 pytestmark = pytest.mark.gpu
 
+# fp32 residual stream after block 0, error as a fraction of the largest |reference| entry
+BERT_STAGE_GUARD = 3e-2
+
 
 def _cos(a, b):
     a, b = a.double(), b.double()
@@ -46,9 +49,14 @@ def test_bert_logits_vs_hf_golden_and_oracle(device, golden_dir, name):
     assert cos_g >= 1 - 1e-3 and cos_o >= 1 - 1e-3          # the contract
     assert cos_g >= 1 - 1e-4 and cos_o >= 1 - 1e-4, (cos_g, cos_o)   # regression guard: ~3x the measured 2e-5 (24 post-LN layers)
     l0 = st["layer0"]
-    assert (tap.cpu().view(N, T, -1) - l0).abs().max().item() <= 3e-2 * l0.abs().max().item()
+    scale = l0.abs().max().item()
+    e_or = (tap.cpu().view(N, T, -1) - l0).abs().max().item() / scale
+    print(f"MEASURED bert {name} layer0 vs oracle {e_or:.3e} (of max |ref|)")
+    assert e_or <= BERT_STAGE_GUARD
     if "layer0" in g:
-        assert np.abs(tap.cpu().view(N, T, -1).numpy() - g["layer0"]).max() <= 3e-2 * l0.abs().max().item()
+        e_go = float(np.abs(tap.cpu().view(N, T, -1).numpy() - g["layer0"]).max()) / scale
+        print(f"MEASURED bert {name} layer0 vs golden {e_go:.3e}")
+        assert e_go <= BERT_STAGE_GUARD
     # the reference's call surface: text_encoder(text).logits, then normalise + cosine logits
     feats = enc(ids.to(device)).logits
     assert torch.equal(feats.cpu(), out)

@@ -33,6 +33,10 @@ def _cos(a, b):
 COS_CONTRACT = 1e-3     # BASELINE.json north_star: "cosine scores within 1e-3 bf16 tolerance"
 COS_GUARD = 3e-5        # ~3x the largest 1 - cos measured on MI355X over every tower / geometry tested here (1e-5)
 COS_GUARD_FOLD = 1e-4   # folded-LayerNorm towers round h instead of LN(h) to bf16: ~3x their measured 3e-5
+# stage taps of the fp32 residual stream, error as a fraction of the largest |reference| entry (bf16 GEMM inputs: errors scale
+# with the row, not the element); vs the HF golden the pixels are additionally bf16-rounded on the device side
+STAGE_GUARD = 2e-2
+STAGE_GUARD_GOLDEN = 3e-2
 
 
 def _check_cos(got, want, what, fold=False):
@@ -148,8 +152,12 @@ def test_layernorm(L, device, d):
     hd, wd, bd = h.to(device), w.to(device), b.to(device)     # keep the device copies alive across the launch
     L.check(L.lib().mmr_debug_layernorm(hd.data_ptr(), wd.data_ptr(), bd.data_ptr(), x.data_ptr(), 37, d, 1e-5,
                                         L.stream_ptr(device)))
-    err = (x.float().cpu() - ref).abs().max().item()
-    assert err <= 1e-2 * ref.abs().max().item(), err
+    # the kernel normalises in fp32 and rounds ONCE to bf16: half an ulp (2^-9 relative) per element; the bound allows a whole
+    # ulp plus an absolute floor for elements near zero (fp32 statistics noise, ~1e-6 of the largest output)
+    got = x.float().cpu()
+    bound = 2.0 ** -8 * ref.abs() + 1e-5 * ref.abs().max().item()
+    excess = ((got - ref).abs() / bound).max().item()
+    assert excess <= 1.0, f"layernorm d={d}: error is {excess:.2f}x the per-element bound"
 
 
 # sequence lengths around every kernel boundary: 16-key MFMA tiles, the 32/64/96-token in-register kernels, the 64-key
@@ -271,9 +279,11 @@ def test_tiny_vision_stages_vs_golden_and_oracle(L, device, golden_dir, fold):
         got = tap.cpu().view(B, T, d)
         ref = st[key]
         scale = ref.abs().max().item()
-        assert (got - ref).abs().max().item() <= 2e-2 * scale, f"stage {key}"
+        e_or, e_go = (got - ref).abs().max().item() / scale, float(np.abs(got.numpy() - g[gold]).max()) / scale
+        print(f"MEASURED stage {key} fold={fold}: vs oracle {e_or:.3e}, vs golden {e_go:.3e} (of max |ref|)")
+        assert e_or <= STAGE_GUARD, f"stage {key}: {e_or:.2e}"
         # and against the HF golden (fp32 pixels): same bound plus the pixel-rounding effect
-        assert np.abs(got.numpy() - g[gold]).max() <= 3e-2 * scale, f"golden {gold}"
+        assert e_go <= STAGE_GUARD_GOLDEN, f"golden {gold}: {e_go:.2e}"
     feat = feat.cpu()
     _check_cos(feat, feat_or, "tiny vision vs oracle", fold)
     _check_cos(feat, torch.from_numpy(g["image_features"]), "tiny vision vs HF golden", fold)
@@ -294,8 +304,11 @@ def test_tiny_text_vs_golden_and_oracle(L, device, golden_dir, fold):
     tap = torch.zeros(N * T, d, device=device)
     feat = tower.forward(ids.to(device), torch.float32, False, 0, tap).cpu()
     ref = st["layer0"]
-    assert (tap.cpu().view(N, T, d) - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
-    assert np.abs(tap.cpu().view(N, T, d).numpy() - g["t_layer0"]).max() <= 2e-2 * ref.abs().max().item()
+    scale = ref.abs().max().item()
+    e_or = (tap.cpu().view(N, T, d) - ref).abs().max().item() / scale
+    e_go = float(np.abs(tap.cpu().view(N, T, d).numpy() - g["t_layer0"]).max()) / scale
+    print(f"MEASURED text layer0 fold={fold}: vs oracle {e_or:.3e}, vs golden {e_go:.3e} (of max |ref|)")
+    assert e_or <= STAGE_GUARD and e_go <= STAGE_GUARD
     _check_cos(feat, feat_or, "tiny text vs oracle", fold)
     _check_cos(feat, torch.from_numpy(g["text_features"]), "tiny text vs HF golden", fold)
 

@@ -88,3 +88,41 @@ def test_preprocess_feeds_encoder(device):
         P.preprocess_image(torch.zeros(4, 4, 3, device=device))
     with pytest.raises(RuntimeError):
         P.preprocess_image(torch.zeros(4, 4, 3, dtype=torch.uint8))
+
+
+@pytest.mark.gpu
+def test_overlapped_gallery_build_equals_serial_and_pillow(device):
+    """the reference's gallery loop preprocess -> encode_image -> normalise -> keep the row
+    (code/search_image.py:153-158) with the preprocess of batch i+1 on a side stream under the encode of batch i:
+    bit-identical to the serial schedule, and to Pillow-exact per-image preprocessing + encode_image; ragged last batch."""
+    import mmr_amd
+    from mmr_amd import gallery, preprocess as P
+    from oracle import preprocess_ref
+    model, _ = mmr_amd.load("tiny-test", device=device)
+    S, E = model.input_resolution, model.cfg.embed_dim
+    H, W = 90, 130
+    g = torch.Generator().manual_seed(5)
+    raws = [torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, generator=g) for n in (6, 6, 6, 6, 3)]   # ragged tail
+    dev_raws = [r.to(device) for r in raws]
+    total = sum(r.shape[0] for r in raws)
+    ovl = gallery.build_gallery_overlapped(model, iter(dev_raws), total=total).clone()
+    ser = gallery.build_gallery_overlapped(model, iter(dev_raws), total=total, overlap=False).clone()
+    assert ovl.shape == (total, E) and ovl.dtype == torch.bfloat16
+    assert torch.equal(ovl, ser)
+    # reference composition: Pillow-exact pixels (oracle) rounded to bf16 -> encode_image(normalize=True) in bf16
+    model.bfloat16()
+    px = torch.stack([preprocess_ref.preprocess(im.numpy(), S) for r in raws for im in r]).bfloat16().to(device)
+    ref = torch.cat([model.encode_image(px[i:i + 6], normalize=True) for i in range(0, total, 6)])
+    model.float()
+    assert torch.equal(ovl, ref)
+    assert model.dtype == torch.float32                       # the caller's dtype setting is restored
+    # the uniform-batch preprocessor alone == the per-image path
+    pre = P.UniformBatchPreprocessor(6, H, W, S, out_dtype=torch.float32, device=device, slots=1)
+    assert torch.equal(pre(dev_raws[0]).cpu(), torch.stack([preprocess_ref.preprocess(im.numpy(), S) for im in raws[0]]))
+    assert gallery.build_gallery_overlapped(model, iter([]), total=0).shape == (0, E)
+    with pytest.raises(ValueError):
+        gallery.build_gallery_overlapped(model, iter(dev_raws))                  # no total / gallery to write into
+    with pytest.raises(ValueError):
+        gallery.build_gallery_overlapped(model, iter(dev_raws), total=7)         # too small
+    with pytest.raises(ValueError):
+        model.encode_image(px[:2].float(), out=torch.empty(3, E, device=device))

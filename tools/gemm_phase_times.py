@@ -17,12 +17,15 @@ st = _lib.stream_ptr(dev)
 L.mmr_debug_gemm_stamps.restype = ctypes.c_int
 L.mmr_debug_gemm_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 shapes = [("qkv", 0, 12800, 2304, 768), ("fc1", 1, 12800, 3072, 768), ("out", 2, 12800, 768, 768), ("fc2", 2, 12800, 768, 3072)]
+if os.environ.get("SHAPES") == "resid":       # the fp32-residual launches of ViT-B/32 batch 256 / 512 and ViT-L/14@336 batch 128
+    shapes = [("out", 2, 12800, 768, 768), ("fc2", 2, 12800, 768, 3072), ("out-b512", 2, 25600, 768, 768),
+              ("L14-out", 2, 73984, 1024, 1024), ("L14-fc2", 2, 73984, 1024, 4096)]
 for name, epi, M, N, K in shapes:
     A = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
     W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
     bias = torch.randn(N, device=dev)
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi >= 2 else torch.bfloat16)
-    for _ in range(int(os.environ.get("WARM", 2000))):       # long enough for the clock to settle under this load
+    for _ in range(max(50, int(os.environ.get("WARM", 2000)) * 12800 // M)):       # long enough for the clock to settle under this load
         _lib.check(L.mmr_debug_gemm(epi, A.data_ptr(), W.data_ptr(), M, N, K, bias.data_ptr(), out.data_ptr(), st))
     torch.cuda.synchronize()
     L.mmr_debug_gemm_stamps(None, 1)
