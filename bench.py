@@ -226,9 +226,10 @@ def build_leg(args, C, custom, dev, rank, world, use_dist, dist):
         return float(t.item()), r
 
     gal = torch.empty(K * B, E, dtype=torch.bfloat16, device=dev)
-    gallery.build_gallery_overlapped(model, batches(Wm + 2), total=(Wm + 2) * B)                 # warm-up (both slots)
-    t_ovl, g_ovl = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal))
+    gallery.build_gallery_overlapped(model, batches(Wm + 2), total=(Wm + 2) * B, overlap=True)   # warm-up (both slots)
+    t_ovl, g_ovl = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal, overlap=True))
     g_ovl = g_ovl.clone()
+    gallery.build_gallery_overlapped(model, batches(2), total=2 * B, overlap=False)
     t_ser, g_ser = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal, overlap=False))
     g_ser = g_ser.clone()
     px = [preprocess.preprocess_batch(list(r), S, out_dtype=torch.bfloat16) for r in raws]
@@ -254,16 +255,17 @@ def build_leg(args, C, custom, dev, rank, world, use_dist, dist):
     gflops, n_gemm = gemm_flops_per_forward(model.cfg.vision, B)
     # roofline of the dominant kernel (the bf16 GEMMs), launch durations from a second, instrumented pass
     _lib.prof_enable(True, max(4096, 300 * K))
-    gallery.build_gallery_overlapped(model, batches(K), gallery=gal)
+    gallery.build_gallery_overlapped(model, batches(K), gallery=gal, overlap=False)
     torch.cuda.synchronize(dev)
     _lib.prof_enable(False)
     prof = _lib.prof_read()
     gemm_ms, gemm_n = prof["gemm"]
     gemm_tflops = gflops * (gemm_n / n_gemm) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     imgs = world * K * B
+    t_best = min(t_ser, t_ovl)
     line = {
-        "metric": METRIC, "value": round(imgs / t_ovl, 1), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": Wm,
-        "ms_per_step": round(t_ovl / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": METRIC, "value": round(imgs / t_best, 1), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": Wm,
+        "ms_per_step": round(t_best / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": (f"gallery build from raw images: {B} uint8 {H}x{W}x3 images/GPU per step (resident) -> bicubic "
                                 f"resize + centre crop + normalise ({S}x{S}, Pillow-exact) -> {C['model']} bf16 encode -> "
@@ -271,17 +273,18 @@ def build_leg(args, C, custom, dev, rank, world, use_dist, dist):
                                 f"{'; CUSTOM ' + ' '.join(custom) if custom else ''})"),
                    "name": "build", "encode_batch_per_gpu": B, "image_hw": [H, W],
                    "parallelism": f"dp{world} (no collective)" if use_dist else "single GPU",
-                   "schedule": "preprocess of batch i+1 on a side stream under the encode of batch i",
+                   "schedule": ("value = the faster of the two schedules measured: back to back on one stream (the library default) / "
+                                "preprocess of batch i+1 on a low-priority side stream under the encode of batch i"),
                    "weights": "seeded random init (no checkpoint reachable offline)"},
         "verify": "ok" if ok else "FAILED",
         "verify_detail": {"overlapped_equals_serial_bitwise": same_ovl, "serial_equals_preprocess_batch_then_encode_bitwise": same_ref},
-        "build_images_per_s": round(imgs / t_ovl, 1), "build_serial_images_per_s": round(imgs / t_ser, 1),
+        "build_overlapped_images_per_s": round(imgs / t_ovl, 1), "build_serial_images_per_s": round(imgs / t_ser, 1),
         "encode_only_images_per_s": round(imgs / t_enc, 1), "preprocess_only_images_per_s": round(imgs / t_pre, 1),
-        "build_over_encode_only": round(t_enc / t_ovl, 4), "serial_over_encode_only": round(t_enc / t_ser, 4),
+        "overlapped_over_encode_only": round(t_enc / t_ovl, 4), "serial_over_encode_only": round(t_enc / t_ser, 4),
         "roofline": {"kernel": "bf16 MFMA GEMMs of the image tower (all epilogues)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
                      "avg_launch_us": round(gemm_ms / gemm_n * 1e3, 2) if gemm_n else None, "launches": gemm_n,
-                     "measured": "HIP event pairs around each launch, second pass (with the preprocess running beside it)"},
+                     "measured": "HIP event pairs around each launch, second pass (serial schedule)"},
     }
     return line, ok
 

@@ -254,6 +254,12 @@ typedef struct {
 } mmr_preprocess_desc;
 int mmr_preprocess_batch(const void *desc, int B, int S, int max_rows, float mean0, float mean1, float mean2,
                          float std0, float std1, float std2, void *out, mmr_dtype out_dtype, void *stream);
+/* Same, with max_width = the widest image of the batch (pixels): lets the horizontal pass stage whole input rows in LDS
+ * (coalesced loads, ~1 global instruction per output pixel instead of 9).  The fast forms need every image's coefficient
+ * rows padded with zero taps to a multiple of 4 (hk % 4 == 0, 16-byte aligned tables: what preprocess.py builds) and
+ * S % 4 == 0; an image that does not qualify takes the byte-wise path inside the same launch.  Results are identical. */
+int mmr_preprocess_batch_ex(const void *desc, int B, int S, int max_rows, int max_width, float mean0, float mean1, float mean2,
+                            float std0, float std1, float std2, void *out, mmr_dtype out_dtype, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Launch profiler (measurement aid for bench.py): HIP event pairs around every kernel launch of a

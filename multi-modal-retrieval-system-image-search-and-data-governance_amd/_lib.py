@@ -84,6 +84,8 @@ def lib():
                                        f32, vp, vp, i32, vp, vp]
     L.mmr_preprocess_batch.restype = i32
     L.mmr_preprocess_batch.argtypes = [vp, i32, i32, i32, f32, f32, f32, f32, f32, f32, vp, i32, vp]
+    L.mmr_preprocess_batch_ex.restype = i32
+    L.mmr_preprocess_batch_ex.argtypes = [vp, i32, i32, i32, i32, f32, f32, f32, f32, f32, f32, vp, i32, vp]
     L.mmr_prof_enable.restype = i32
     L.mmr_prof_enable.argtypes = [i32, i32]
     L.mmr_prof_read.restype = i32

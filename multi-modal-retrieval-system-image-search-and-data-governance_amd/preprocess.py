@@ -41,11 +41,12 @@ def _bicubic(x: float) -> float:
 def resample_tables(in_size: int, out_size: int, first: int, count: int) -> Tuple[np.ndarray, np.ndarray, int]:
     """Pillow's precompute_coeffs + normalize_coeffs_8bpc for outputs [first, first+count) of a
     full-box resize in_size -> out_size.  Returns (bounds int32[count,2] = (xmin, taps),
-    coeffs int32[count, ksize], ksize)."""
+    coeffs int32[count, ksize], ksize); ksize is Pillow's, rounded up to a multiple of 4 (zero taps)."""
     scale = float(np.float32(in_size) - np.float32(0.0)) / out_size      # (double)(in1 - in0) / outSize, box is float
     filterscale = max(scale, 1.0)
     support = 2.0 * filterscale                                          # bicubic support = 2
     ksize = int(math.ceil(support)) * 2 + 1
+    ksize = (ksize + 3) // 4 * 4          # rows padded with zero taps to whole groups of 4: the kernels read 4 taps per load
     bounds = np.zeros((count, 2), np.int32)
     coeffs = np.zeros((count, ksize), np.int32)
     ss = 1.0 / filterscale
@@ -68,6 +69,8 @@ def resample_tables(in_size: int, out_size: int, first: int, count: int) -> Tupl
         for x, w in enumerate(k):
             coeffs[j, x] = int(-0.5 + w * (1 << PRECISION_BITS)) if w < 0 else int(0.5 + w * (1 << PRECISION_BITS))
         bounds[j] = (xmin, xmax)
+    # the kernels multiply with the 24-bit integer multiplier: |coefficient| <= 2^22 * |weight|, |weight| <= ~1.2 for bicubic
+    assert int(np.abs(coeffs).max(initial=0)) < (1 << 23), "resample coefficient outside the 24-bit multiplier's range"
     return bounds, coeffs, ksize
 
 
@@ -172,9 +175,9 @@ def preprocess_batch(images: Sequence[torch.Tensor], n_px: int = 224, out_dtype:
     desc_d = torch.from_numpy(desc).to(dev)
     out = torch.empty(B, 3, n_px, n_px, dtype=out_dtype, device=dev)
     L = _lib.lib()
-    _lib.check(L.mmr_preprocess_batch(desc_d.data_ptr(), B, n_px, int(max(rows)), float(mean[0]), float(mean[1]),
-                                      float(mean[2]), float(std[0]), float(std[1]), float(std[2]), out.data_ptr(),
-                                      _lib.dtype_code(out_dtype), _lib.stream_ptr(dev)))
+    _lib.check(L.mmr_preprocess_batch_ex(desc_d.data_ptr(), B, n_px, int(max(rows)), int(max(im.shape[1] for im in imgs)),
+                                         float(mean[0]), float(mean[1]), float(mean[2]), float(std[0]), float(std[1]),
+                                         float(std[2]), out.data_ptr(), _lib.dtype_code(out_dtype), _lib.stream_ptr(dev)))
     # descriptors, tables and images must outlive the launch: tie them to the output's lifetime
     out._mmr_keepalive = (desc_d, tmp, imgs)
     return out
@@ -228,8 +231,8 @@ class UniformBatchPreprocessor:
         sl["desc_d"][:b].copy_(sl["desc_h"][:b], non_blocking=True)
         out = sl["out"][:b]
         L = _lib.lib()
-        _lib.check(L.mmr_preprocess_batch(sl["desc_d"].data_ptr(), b, self.S, int(self.rows), float(self.mean[0]),
-                                          float(self.mean[1]), float(self.mean[2]), float(self.std[0]), float(self.std[1]),
-                                          float(self.std[2]), out.data_ptr(), _lib.dtype_code(self.out_dtype),
-                                          _lib.stream_ptr(self.device)))
+        _lib.check(L.mmr_preprocess_batch_ex(sl["desc_d"].data_ptr(), b, self.S, int(self.rows), self.W, float(self.mean[0]),
+                                             float(self.mean[1]), float(self.mean[2]), float(self.std[0]), float(self.std[1]),
+                                             float(self.std[2]), out.data_ptr(), _lib.dtype_code(self.out_dtype),
+                                             _lib.stream_ptr(self.device)))
         return out

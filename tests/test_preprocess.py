@@ -105,7 +105,7 @@ def test_overlapped_gallery_build_equals_serial_and_pillow(device):
     raws = [torch.randint(0, 256, (n, H, W, 3), dtype=torch.uint8, generator=g) for n in (6, 6, 6, 6, 3)]   # ragged tail
     dev_raws = [r.to(device) for r in raws]
     total = sum(r.shape[0] for r in raws)
-    ovl = gallery.build_gallery_overlapped(model, iter(dev_raws), total=total).clone()
+    ovl = gallery.build_gallery_overlapped(model, iter(dev_raws), total=total, overlap=True).clone()
     ser = gallery.build_gallery_overlapped(model, iter(dev_raws), total=total, overlap=False).clone()
     assert ovl.shape == (total, E) and ovl.dtype == torch.bfloat16
     assert torch.equal(ovl, ser)
