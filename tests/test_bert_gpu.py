@@ -12,8 +12,9 @@ from mmr_amd.config import get_bert_config
 
 pytestmark = pytest.mark.gpu
 
-# fp32 residual stream after block 0, error as a fraction of the largest |reference| entry
-BERT_STAGE_GUARD = 3e-2
+# fp32 residual stream after block 0, error as a fraction of the largest |reference| entry; ~3x the measured 1.2e-4 (tiny
+# geometry) / 1.3e-3 (BERT-large geometry)
+BERT_STAGE_GUARD = 4e-3
 
 
 def _cos(a, b):

@@ -35,8 +35,11 @@ COS_GUARD = 3e-5        # ~3x the largest 1 - cos measured on MI355X over every 
 COS_GUARD_FOLD = 1e-4   # folded-LayerNorm towers round h instead of LN(h) to bf16: ~3x their measured 3e-5
 # stage taps of the fp32 residual stream, error as a fraction of the largest |reference| entry (bf16 GEMM inputs: errors scale
 # with the row, not the element); vs the HF golden the pixels are additionally bf16-rounded on the device side
-STAGE_GUARD = 2e-2
-STAGE_GUARD_GOLDEN = 3e-2
+# Guards = ~3x what MI355X measures (round 3, both LayerNorm modes): vision stages 5e-7 (pre-LN) .. 1.7e-3 vs the oracle on
+# the same bf16-rounded pixels, 2.0e-3 .. 3.0e-3 vs the HF golden (fp32 pixels); text layer 0: 4.3e-3 .. 5.1e-3
+STAGE_GUARD = 6e-3
+STAGE_GUARD_GOLDEN = 1e-2
+STAGE_GUARD_TEXT = 1.6e-2
 
 
 def _check_cos(got, want, what, fold=False):
@@ -308,7 +311,7 @@ def test_tiny_text_vs_golden_and_oracle(L, device, golden_dir, fold):
     e_or = (tap.cpu().view(N, T, d) - ref).abs().max().item() / scale
     e_go = float(np.abs(tap.cpu().view(N, T, d).numpy() - g["t_layer0"]).max()) / scale
     print(f"MEASURED text layer0 fold={fold}: vs oracle {e_or:.3e}, vs golden {e_go:.3e} (of max |ref|)")
-    assert e_or <= STAGE_GUARD and e_go <= STAGE_GUARD
+    assert e_or <= STAGE_GUARD_TEXT and e_go <= STAGE_GUARD_TEXT
     _check_cos(feat, feat_or, "tiny text vs oracle", fold)
     _check_cos(feat, torch.from_numpy(g["text_features"]), "tiny text vs HF golden", fold)
 

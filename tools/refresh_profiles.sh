@@ -4,7 +4,7 @@
 #   separate runs, kernel trace only), bench lines of the other BASELINE configs at N = 1, small-batch latency with and
 #   without hipGraph replay, the L2 / Infinity-Cache / HBM fetch-rate probe with the GEMM kernels' L2 hit/miss counters,
 #   and the in-kernel phase breakdown of the GEMM tiles (diagnostic build, if tools/libmmr_hip_stamps.so is present).
-R=${R:-r02}
+R=${R:-r03}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out
 rm -rf $O/prof_bench $O/pmc_fetch $O/pmc_write
@@ -25,6 +25,10 @@ for c in cfg3 cfg4 cfg5; do
   timeout -k 10 300 python bench.py --config $c --steps 10 --warmup 3 > $O/${R}_bench_$c.json 2> $O/${R}_bench_$c.err || echo "bench $c failed"
   echo "bench $c done"
 done
+# the N > 1 code path (process group, RCCL all-gather, pipelined steps) with ONE self-spawned rank, and the gallery build leg
+timeout -k 10 300 python bench.py --gpus 1 --spawn --steps 20 --warmup 5 > $O/${R}_bench_spawn1.json 2> $O/${R}_bench_spawn1.err || echo "bench spawn1 failed"
+timeout -k 10 300 python bench.py --config build --steps 20 --warmup 3 > $O/${R}_bench_build.json 2> $O/${R}_bench_build.err || echo "bench build failed"
+echo "spawn1 + build done"
 rm -rf $O/prof_cfg5
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg5 -- python bench.py --config cfg5 --steps 5 --warmup 2 > /dev/null 2> $O/prof_cfg5.err \
     && cp $(ls $O/prof_cfg5/*/*kernel_stats.csv | head -1) $O/${R}_bench_cfg5_kernel_stats.csv
