@@ -19,7 +19,7 @@ int launch_gemm_patch32(const bf16_t *pix, int B, int S, const bf16_t *W, int M,
 int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, const GemmAux &aux, hipStream_t st);
 // vit_ops.hip
 int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P, int G, int K, int Kpad, hipStream_t st);
-int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h, int B, int T, int d, float eps, bf16_t *xb, float2 *stats, hipStream_t st);
+int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h, int B, int T, int d, float eps, bf16_t *xb, float2 *stats, int32_t *status, hipStream_t st);
 int launch_embed_text(const int32_t *ids, const bf16_t *tok, const float *pos, float *h, int Nb, int T, int d, int vocab, bf16_t *xb, float2 *stats, int32_t *status, hipStream_t st);
 int launch_layernorm(const float *h, const float *w, const float *b, bf16_t *x, int64_t rows, int d, float eps, hipStream_t st);
 int launch_pool_ln(const float *h, const int32_t *ids, const float *w, const float *b, bf16_t *xc, int Nb, int T, int d, float eps, hipStream_t st);
@@ -252,7 +252,8 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
     float2 *stats = fold ? (float2 *)(ws + p.off_stats) : nullptr;
     bf16_t *xb = fold ? x : nullptr;
     int32_t *status = (int32_t *)(ws + p.off_status);
-    MMR_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
+    // text: the embedding kernel ORs bits into the word, so it is cleared ahead of it; vision: cleared BY the embedding kernel
+    if (c.kind != 0) MMR_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int32_t), st));
 
     // ---- embeddings
     if (c.kind == 0) {
@@ -267,7 +268,7 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
         }
         if (rc) return rc;
         if ((rc = launch_embed_vision(pe, t->g<float>(MMR_P_CLS), t->g<float>(MMR_P_POS), t->g<float>(MMR_P_LN_PRE_W),
-                                      t->g<float>(MMR_P_LN_PRE_B), h, B, T, d, c.ln_eps, xb, stats, st))) return rc;
+                                      t->g<float>(MMR_P_LN_PRE_B), h, B, T, d, c.ln_eps, xb, stats, status, st))) return rc;
     } else {
         if ((rc = launch_embed_text((const int32_t *)input, t->g<bf16_t>(MMR_P_TOK_EMB), t->g<float>(MMR_P_POS), h, B, T, d,
                                     c.vocab, xb, stats, status, st))) return rc;

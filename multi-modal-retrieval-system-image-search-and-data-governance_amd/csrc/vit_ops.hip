@@ -114,9 +114,12 @@ __global__ __launch_bounds__(256) void embed_vision_kernel(const float *__restri
                                                            const float *__restrict__ pos, const float *__restrict__ lw,
                                                            const float *__restrict__ lb, float *__restrict__ h, int B,
                                                            int T, int d, float eps, bf16_t *__restrict__ xb,
-                                                           float2 *__restrict__ stats)
+                                                           float2 *__restrict__ stats, int32_t *__restrict__ status)
 {
     const int lane = threadIdx.x & 63;
+    // the workspace's status word (include/mmr.h): nothing in a vision forward can raise a bit, so the word is zeroed
+    // here instead of by a memset launch of its own (one dependent launch less on the batch-1 path)
+    if (blockIdx.x == 0 && threadIdx.x == 0) *status = 0;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (int64_t)B * T) return;
     const int t = (int)(row % T);
@@ -843,11 +846,11 @@ int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P,
 }
 
 int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h,
-                        int B, int T, int d, float eps, bf16_t *xb, float2 *stats, hipStream_t st)
+                        int B, int T, int d, float eps, bf16_t *xb, float2 *stats, int32_t *status, hipStream_t st)
 {
     ProfScope prof(MMR_PROF_ROWWISE, st);
     const dim3 grid((unsigned)(((int64_t)B * T + 3) / 4));
-    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_vision_kernel<VPL>, grid, dim3(256), 0, st, pe, cls, pos, lw, lb, h, B, T, d, eps, xb, stats));
+    MMR_VPL_SWITCH(d, hipLaunchKernelGGL(embed_vision_kernel<VPL>, grid, dim3(256), 0, st, pe, cls, pos, lw, lb, h, B, T, d, eps, xb, stats, status));
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
