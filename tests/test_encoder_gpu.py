@@ -651,3 +651,44 @@ def test_vit_l14_336_batch_128_configs4_shape(device):
     gal = synth.synth_unit_rows(20_000, 768, seed=9).bfloat16().to(device)
     vals, idx = mmr_amd.cosine_topk(f, gal, 10)
     assert idx.shape == (128, 10) and (idx >= 0).all()
+
+
+@pytest.mark.parametrize("T,causal,masked", [(50, 0, 0), (77, 1, 0), (33, 0, 1), (96, 0, 0), (16, 1, 0), (1, 0, 0)])
+def test_short_attention_many_pairs_per_workgroup_is_bitwise_the_small_launch(L, device, T, causal, masked):
+    """The T <= 96 kernel is persistent: a workgroup walks (sequence, head) pairs blockIdx.x + k * grid with the next pair's
+    K/V prefetched by LDS-DMA into the other LDS image.  A launch with several pairs per workgroup (B x heads far above the
+    resident workgroup count) must return, per sequence, the bits of a launch where every workgroup has ONE pair, and both
+    stay within the usual bound of the fp32 reference; an odd pair count leaves the last round ragged."""
+    heads = 4
+    B = 1733                                          # 6932 pairs: 5-6 per workgroup, not a multiple of any grid
+    d = heads * 64
+    g = torch.Generator().manual_seed(11 * T + causal + 2 * masked)
+    qkv = (torch.randn(B * T, 3 * d, generator=g) * 1.5).bfloat16().to(device)
+    mask = None
+    if masked:
+        lens = torch.randint(1, T + 1, (B,), generator=g)
+        mask = (torch.arange(T)[None, :] < lens[:, None]).int().to(device)
+
+    def run(b0, nb):
+        o = torch.zeros(nb * T, d, dtype=torch.bfloat16, device=device)
+        q = qkv[b0 * T:(b0 + nb) * T]
+        if masked:
+            m = mask[b0:b0 + nb].contiguous()
+            L.check(L.lib().mmr_debug_attention_masked(q.data_ptr(), o.data_ptr(), nb, T, heads, m.data_ptr(), L.stream_ptr(device)))
+        else:
+            L.check(L.lib().mmr_debug_attention(q.data_ptr(), o.data_ptr(), nb, T, heads, causal, L.stream_ptr(device)))
+        return o
+
+    big = run(0, B)
+    for b0 in (0, 641, B - 3):
+        assert torch.equal(big[b0 * T:(b0 + 3) * T], run(b0, 3)), b0
+    sl = slice(1000 * T, 1040 * T)
+    q, k, v = qkv[sl].float().view(40, T, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    att = (q @ k.transpose(-1, -2)) * 0.125
+    if causal:
+        att = att + torch.full((T, T), float("-inf"), device=device).triu(1)
+    if masked:
+        att = att.masked_fill(mask[1000:1040].view(40, 1, 1, T) == 0, float("-inf"))
+    ref = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(40 * T, d)
+    err = (big[sl].float() - ref).abs().max().item()
+    assert err <= 1.3e-2 * ref.abs().max().item() + 1e-4, f"T={T}: {err / ref.abs().max().item():.2e} of max"

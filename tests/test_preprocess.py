@@ -126,3 +126,42 @@ def test_overlapped_gallery_build_equals_serial_and_pillow(device):
         gallery.build_gallery_overlapped(model, iter(dev_raws), total=7)         # too small
     with pytest.raises(ValueError):
         model.encode_image(px[:2].float(), out=torch.empty(3, E, device=device))
+
+
+@pytest.mark.gpu
+def test_fast_preprocess_paths_edge_cases(device):
+    """Round 3's kernels read 12 / 16 bytes at a time where round 2 read single bytes: the cases where that could go wrong.
+      * images whose bytes start at an ODD address (a slice of a flat buffer) and END at the last byte of their allocation
+        (the window of the last row's rightmost column must not read past it: the bounded byte-wise path);
+      * very wide images (fewer rows fit the LDS stage; > 21 845 pixels wide: the non-staged 12-byte path);
+      * an output size that is not a multiple of 4 (the generic vertical pass), tiny sources (up-scaling: 1-2 taps);
+      * mixed batches (different widths, one launch pair) and the UniformBatchPreprocessor on the same images."""
+    from mmr_amd import preprocess as P
+    from oracle import preprocess_ref
+    cases = [(40, 33), (50, 7000), (8, 22000), (5, 5), (231, 501), (33, 40)]
+    for h, w in cases:
+        img = _img(h, w, seed=h * 7 + w)
+        n = h * w * 3
+        flat = torch.zeros(n + 1, dtype=torch.uint8, device=device)          # image = the LAST n bytes, starting at offset 1
+        flat[1:] = torch.from_numpy(img).reshape(-1).to(device)
+        view = flat[1:].view(h, w, 3)
+        assert view.data_ptr() % 2 == 1 or view.data_ptr() % 16 != 0
+        for n_px in (224, 64, 30):                                           # 30: not a multiple of 4
+            out, u8 = P.preprocess_image(view, n_px, return_u8=True)
+            assert np.array_equal(u8.cpu().numpy(), preprocess_ref.preprocess_u8(img, n_px)), (h, w, n_px)
+            assert torch.equal(out.cpu(), preprocess_ref.preprocess(img, n_px)), (h, w, n_px)
+    imgs = [_img(h, w, seed=3 * h + w) for h, w in [(60, 90), (90, 60), (50, 7000), (224, 224)]]
+    dev_imgs = [torch.from_numpy(a).to(device) for a in imgs]
+    for n_px in (224, 30):
+        got = P.preprocess_batch(dev_imgs, n_px, out_dtype=torch.float32)
+        ref = torch.stack([preprocess_ref.preprocess(a, n_px) for a in imgs])
+        assert torch.equal(got.cpu(), ref), n_px
+    same = np.stack([_img(77, 131, seed=s) for s in range(5)])
+    pre = P.UniformBatchPreprocessor(8, 77, 131, 64, out_dtype=torch.float32, device=device, slots=2)
+    for slot in (0, 1):
+        got = pre(torch.from_numpy(same).to(device), slot)
+        assert torch.equal(got.cpu(), torch.stack([preprocess_ref.preprocess(a, 64) for a in same]))
+    with pytest.raises(ValueError):
+        pre(torch.zeros(9, 77, 131, 3, dtype=torch.uint8, device=device))
+    with pytest.raises(ValueError):
+        pre(torch.zeros(2, 77, 130, 3, dtype=torch.uint8, device=device))
