@@ -257,7 +257,10 @@ int mmr_preprocess_batch(const void *desc, int B, int S, int max_rows, float mea
 /* Same, with max_width = the widest image of the batch (pixels): lets the horizontal pass stage whole input rows in LDS
  * (coalesced loads, ~1 global instruction per output pixel instead of 9).  The fast forms need every image's coefficient
  * rows padded with zero taps to a multiple of 4 (hk % 4 == 0, 16-byte aligned tables: what preprocess.py builds) and
- * S % 4 == 0; an image that does not qualify takes the byte-wise path inside the same launch.  Results are identical. */
+ * S % 4 == 0; an image that does not qualify takes the byte-wise path inside the same launch.  Results are identical.
+ * PRECONDITION of the fast forms: |coefficient| < 2^23 (they multiply on the 24-bit integer multiplier) -- true for every
+ * table Pillow's normalize_coeffs_8bpc can produce (22 fractional bits, |weight| <= ~1.2); a caller with other tables
+ * leaves hk unpadded (hk % 4 != 0) to stay on the 32-bit byte-wise path.  Nothing is read past the last byte of an image. */
 int mmr_preprocess_batch_ex(const void *desc, int B, int S, int max_rows, int max_width, float mean0, float mean1, float mean2,
                             float std0, float std1, float std2, void *out, mmr_dtype out_dtype, void *stream);
 
