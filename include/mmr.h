@@ -77,6 +77,17 @@ int mmr_cosine_topk_ex(const void *q, const void *gallery, mmr_dtype dtype, int 
                        float *score, double *dot64, int32_t *status, void *workspace, size_t workspace_bytes,
                        void *stream);
 
+/* fp32 galleries that are searched many times: split the gallery ONCE into hi = bf16(x) and lo = bf16(x - hi) (two bf16
+ * arrays [N,E], together the bytes of the fp32 gallery), then search with mmr_cosine_topk_split -- the scan streams the two
+ * arrays and skips the per-tile split mmr_cosine_topk performs on fp32 rows (1M x 512 x 128 queries: 0.60 -> see DESIGN.md);
+ * the exact fp64 re-score still reads the fp32 gallery, so results are IDENTICAL to mmr_cosine_topk_ex(..., MMR_F32, ...).
+ * The split arrays must come from mmr_gallery_split_bf16 of the SAME gallery contents. */
+int mmr_gallery_split_bf16(const float *gallery, int64_t N, int E, void *hi, void *lo, void *stream);
+int mmr_cosine_topk_split(const void *q, const void *gallery, const void *gallery_hi, const void *gallery_lo, int Q,
+                          int64_t N, int E, int k, float scale, float gallery_norm_bound, const float *gallery_norm_bound_dev,
+                          int32_t *idx, float *score, double *dot64, int32_t *status, void *workspace, size_t workspace_bytes,
+                          void *stream);
+
 /* out[Q,N] (fp32) = (float)(dot64 * scale): the materialised score matrix for small N. */
 int mmr_similarity(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, float scale,
                    float *out, void *stream);

@@ -682,6 +682,141 @@ __global__ __launch_bounds__(ScanF32sCfg<E>::SCAN_THREADS, ScanF32sCfg<E>::SCAN_
 }
 
 // ---------------------------------------------------------------------------------------------
+// fp32 galleries that are searched many times (GalleryIndex): the hi / lo split of the gallery is done ONCE, into two bf16
+// arrays (together the bytes of the fp32 gallery), and the scan streams those.  scan_f32s_kernel spends its time above the
+// HBM stream on the split itself: 24 VALU instructions per 8 values, the images' LDS writes and a second barrier per tile
+// (0.60 ms for 1M x 512 x 128 queries against 0.35 ms of HBM time); here a tile arrives by LDS-DMA already as the two
+// images scan_f32s builds, there is one barrier per tile, and what is left is the three MFMAs per k-step.  Same split
+// function, hence the same MFMA operands, the same bucket maxima and the same candidates; the exact re-score still reads
+// the fp32 gallery.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void split_gallery_kernel(const float *__restrict__ g, int64_t n8, bf16_t *__restrict__ hi,
+                                                            bf16_t *__restrict__ lo)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one unit = 8 consecutive values
+    if (i >= n8) return;
+    const float4 a0 = *reinterpret_cast<const float4 *>(g + i * 8), a1 = *reinterpret_cast<const float4 *>(g + i * 8 + 4);
+    bf16x8 h, l;
+    split_bf16x8(a0, a1, h, l);
+    *reinterpret_cast<bf16x8 *>(hi + i * 8) = h;
+    *reinterpret_cast<bf16x8 *>(lo + i * 8) = l;
+}
+
+template <int E>
+__global__ __launch_bounds__(ScanF32sCfg<E>::SCAN_THREADS, ScanF32sCfg<E>::SCAN_WAVES / 4) void scan_split_kernel(
+    const float *__restrict__ q, const bf16_t *__restrict__ ghi, const bf16_t *__restrict__ glo, int Q, int64_t N, int ntiles,
+    int tpt, int qwaves, int qpad, float *__restrict__ bmax, float *__restrict__ tmax)
+{
+    using C = ScanF32sCfg<E>;
+    constexpr int SNBUF = C::NBUF;          // a fourth ring slot and fragment reads six k-steps ahead both measured no faster
+    static_assert(2 * C::IMG_BYTES == C::TILE_BYTES, "a ring slot holds the hi and the lo image of one 16-row tile");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, g = lane >> 4;
+    const int task = blockIdx.x;
+    const int t0 = task * tpt;
+    const int t1 = min(ntiles, t0 + tpt);
+    const bool compute = wave < qwaves;
+
+    bf16x8 bqh[C::KSTEPS], bql[C::KSTEPS];     // query (wave*16 + r), elements [32s + 8g, +8), split
+    {
+        const int qrow = wave * 16 + r;
+        const bool live = compute && qrow < Q;
+        const float *qp = q + (size_t)(live ? qrow : 0) * E + g * 8;
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            float4 a0 = *reinterpret_cast<const float4 *>(qp + s * 32), a1 = *reinterpret_cast<const float4 *>(qp + s * 32 + 4);
+            if (!live) { a0 = make_float4(0.f, 0.f, 0.f, 0.f); a1 = a0; }
+            split_bf16x8(a0, a1, bqh[s], bql[s]);
+        }
+    }
+    // one ring slot = [hi image | lo image], each [16 rows][E bf16] with scan_f32s' chunk swizzle, lane-linear for LDS-DMA
+    auto stage = [&](int tile, int buf) {
+#pragma unroll
+        for (int i = 0; i < C::LPW; ++i) {
+            const int instr = wave * C::LPW + i;
+            const int p = instr * 64 + lane;
+            const int im = p / (TILE_ROWS_F32 * C::CHB);          // 0 = hi, 1 = lo (wave-instruction uniform)
+            const int pp = p - im * (TILE_ROWS_F32 * C::CHB);
+            const int row = pp / C::CHB;
+            const int pos = pp % C::CHB;
+            const int chunk = (pos & ~15) | ((pos ^ row) & 15);
+            int64_t grow = (int64_t)tile * TILE_ROWS_F32 + row;
+            grow = grow < N ? grow : N - 1;
+            glds16((im ? glo : ghi) + grow * E + chunk * 8, smem + buf * C::TILE_BYTES + instr * 1024);
+        }
+    };
+    float task_max = -INFINITY, pend = -INFINITY;
+    int pend_tile = -1;
+    auto compute_tile = [&](int t, int slot) {
+        const char *img_hi = smem + slot * C::TILE_BYTES, *img_lo = img_hi + C::IMG_BYTES;
+        const int rowoff = r * (E * 2);
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f}, acc2 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc3 = (f32x4){0.f, 0.f, 0.f, 0.f};
+        constexpr int PF = C::KSTEPS < 3 ? C::KSTEPS : 3;
+        bf16x8 fh[PF], fl[PF];
+        auto issue = [&](int s, bf16x8 &dh, bf16x8 &dl) {
+            const int c = 4 * s + g;
+            const int off = rowoff + (((c & ~15) | ((c ^ r) & 15)) << 4);
+            const uint32_t ah = (uint32_t)(uintptr_t)(img_hi + off), al = (uint32_t)(uintptr_t)(img_lo + off);
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dh) : "v"(ah));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(dl) : "v"(al));
+        };
+#pragma unroll
+        for (int s = 0; s < PF && s < C::KSTEPS; ++s) issue(s, fh[s], fl[s]);
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            const int younger_s = (C::KSTEPS - 1 - s) < (PF - 1) ? (C::KSTEPS - 1 - s) : (PF - 1);
+            bf16x8 &ah = fh[s % PF], &al = fl[s % PF];
+            if (younger_s == 5) asm volatile("s_waitcnt lgkmcnt(10)" : "+v"(ah), "+v"(al));
+            else if (younger_s == 4) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(ah), "+v"(al));
+            else if (younger_s == 3) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(ah), "+v"(al));
+            else if (younger_s == 2) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(ah), "+v"(al));
+            else if (younger_s == 1) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(ah), "+v"(al));
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ah), "+v"(al));
+            // the same three accumulation chains, in the same order, as scan_f32s_kernel: identical bucket maxima
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bqh[s], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bqh[s], acc2, 0, 0, 0);
+            acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bql[s], acc3, 0, 0, 0);
+            if (s + PF < C::KSTEPS) {
+                asm volatile("" : "+v"(acc), "+v"(acc2), "+v"(acc3));
+                issue(s + PF, ah, al);
+            }
+        }
+        float m = -INFINITY;
+        const int64_t base = (int64_t)t * TILE_ROWS_F32 + 4 * g;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m = fmaxf(m, base + i < N ? acc[i] + (acc2[i] + acc3[i]) : -INFINITY);
+        m = fmaxf(m, __shfl_xor(m, 16, 64));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        task_max = fmaxf(task_max, m);
+        pend = m;
+        pend_tile = t;
+    };
+    constexpr int PD = SNBUF - 1;
+#pragma unroll
+    for (int i = 0; i < PD; ++i)
+        if (t0 + i < t1) stage(t0 + i, i);
+    int cur = 0;
+    for (int t = t0; t < t1; ++t) {
+        const int younger = min(PD - 1, t1 - 1 - t);
+        if (younger >= 2) wait_vmcnt<2 * C::LPW>();
+        else if (younger == 1) wait_vmcnt<C::LPW>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();            // tile t landed for every wave; every wave is done with tile t-1's slot
+        if (compute && pend_tile >= 0 && g == 0) bmax[(size_t)pend_tile * qpad + wave * 16 + r] = pend;
+        int nxt = cur + PD; nxt = nxt >= SNBUF ? nxt - SNBUF : nxt;
+        if (t + PD < t1) stage(t + PD, nxt);
+        if (compute) compute_tile(t, cur);
+        cur = cur + 1 >= SNBUF ? 0 : cur + 1;
+    }
+    if (compute && g == 0) {
+        if (pend_tile >= 0) bmax[(size_t)pend_tile * qpad + wave * 16 + r] = pend;
+        tmax[(size_t)task * qpad + wave * 16 + r] = task_max;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // exact fp64 dot, shared by finalize / exhaustive / similarity
 // ---------------------------------------------------------------------------------------------
 // A row of E elements is 64 contiguous chunks of PER = E/64 elements.  load_chunk fetches chunk
@@ -1665,6 +1800,24 @@ static int launch_scan_f32s(const float *q, const float *gal, int Qc, int64_t N,
     return MMR_OK;
 }
 
+template <int E>
+static int launch_scan_split(const float *q, const bf16_t *ghi, const bf16_t *glo, int Qc, int64_t N, const SearchPlan &p, int qpad,
+                             float *bmax, float *tmax, hipStream_t st)
+{
+    ProfScope prof(MMR_PROF_SCAN, st);
+    using C = ScanF32sCfg<E>;
+    const int lds = C::NBUF * C::TILE_BYTES;
+    static DeviceOnce once;
+    if (once.first()) {
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&scan_split_kernel<E>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    }
+    hipLaunchKernelGGL(scan_split_kernel<E>, dim3(p.ntasks), dim3(C::SCAN_THREADS), lds, st, q, ghi, glo, Qc, N, p.ntiles, p.tpt,
+                       qpad / 16, qpad, bmax, tmax);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
 template <typename T, int PER>
 static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, const SearchPlan &p, int qpad,
                            const float *bmax, const float *tmax, float scale, float eps_rel, float host_bound,
@@ -1745,7 +1898,8 @@ extern "C" int mmr_gallery_norm_bound(const void *gallery, mmr_dtype dtype, int6
 
 static int cosine_topk_impl(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
                             float scale, float gallery_norm_bound, const float *norm_bound_dev, int32_t *idx, float *score,
-                            double *dot64, int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+                            double *dot64, int32_t *status, void *workspace, size_t workspace_bytes, void *stream,
+                            const bf16_t *split_hi = nullptr, const bf16_t *split_lo = nullptr)
 {
     MMR_CHECK_ARG(dtype == MMR_F32 || dtype == MMR_BF16, "mmr_cosine_topk: dtype %d", (int)dtype);
     MMR_CHECK_ARG(Q >= 0 && N >= 0, "mmr_cosine_topk: negative size Q=%d N=%lld", Q, (long long)N);
@@ -1811,7 +1965,14 @@ static int cosine_topk_impl(const void *q, const void *gallery, mmr_dtype dtype,
             } else {
                 // MMR_SCAN_F32=exact keeps the fp32-MFMA scan (exact fma chain, 1/16 of the bf16 rate) for A/B comparisons
                 static const bool exact_f32 = getenv("MMR_SCAN_F32") && !strcmp(getenv("MMR_SCAN_F32"), "exact");
-                if (exact_f32) {
+                if (split_hi && split_lo && !exact_f32) {        // the caller holds the gallery's hi / lo split (mmr_gallery_split_bf16)
+                    switch (E) {
+                        case 128: rc = launch_scan_split<128>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st); break;
+                        case 256: rc = launch_scan_split<256>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st); break;
+                        case 512: rc = launch_scan_split<512>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st); break;
+                        default: rc = launch_scan_split<768>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st); break;
+                    }
+                } else if (exact_f32) {
                     switch (E) {
                         case 128: rc = launch_scan_f32<128>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
                         case 256: rc = launch_scan_f32<256>((const float *)qc, (const float *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
@@ -1898,6 +2059,31 @@ extern "C" int mmr_cosine_topk_ex(const void *q, const void *gallery, mmr_dtype 
 {
     return cosine_topk_impl(q, gallery, dtype, Q, N, E, k, scale, gallery_norm_bound, gallery_norm_bound_dev, idx, score,
                             dot64, status, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mmr_gallery_split_bf16(const float *gallery, int64_t N, int E, void *hi, void *lo, void *stream)
+{
+    MMR_CHECK_ARG(N >= 0 && E >= 8 && E % 8 == 0, "mmr_gallery_split_bf16: bad shape N=%lld E=%d", (long long)N, E);
+    if (N == 0) return MMR_OK;
+    MMR_CHECK_ARG(gallery && hi && lo, "mmr_gallery_split_bf16: null pointer");
+    MMR_CHECK_ARG((((uintptr_t)gallery | (uintptr_t)hi | (uintptr_t)lo) & 15) == 0, "mmr_gallery_split_bf16: pointers must be 16-byte aligned");
+    const int64_t n8 = N * (E / 8);
+    MMR_CHECK_ARG((n8 + 255) / 256 < 0x7fffffff, "mmr_gallery_split_bf16: gallery too large for one launch");
+    hipLaunchKernelGGL(split_gallery_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gallery, n8,
+                       (bf16_t *)hi, (bf16_t *)lo);
+    MMR_CHECK_LAUNCH();
+    return MMR_OK;
+}
+
+extern "C" int mmr_cosine_topk_split(const void *q, const void *gallery, const void *gallery_hi, const void *gallery_lo, int Q,
+                                     int64_t N, int E, int k, float scale, float gallery_norm_bound,
+                                     const float *gallery_norm_bound_dev, int32_t *idx, float *score, double *dot64,
+                                     int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+{
+    MMR_CHECK_ARG((gallery_hi && gallery_lo) || N == 0, "mmr_cosine_topk_split: null split arrays");
+    MMR_CHECK_ARG((((uintptr_t)gallery_hi | (uintptr_t)gallery_lo) & 15) == 0, "mmr_cosine_topk_split: split arrays must be 16-byte aligned");
+    return cosine_topk_impl(q, gallery, MMR_F32, Q, N, E, k, scale, gallery_norm_bound, gallery_norm_bound_dev, idx, score, dot64,
+                            status, workspace, workspace_bytes, stream, (const bf16_t *)gallery_hi, (const bf16_t *)gallery_lo);
 }
 
 extern "C" int mmr_similarity(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, float scale,

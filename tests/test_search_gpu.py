@@ -443,3 +443,45 @@ def test_c_abi_rccl_allgather_of_topk(S, oracle, device):
         assert L.mmr_allgather_topk_packed(comm, 0, 12, 10, parts.data_ptr(), 0) == -22
     finally:
         L.mmr_comm_destroy(comm)
+
+
+@pytest.mark.parametrize("E", [128, 512, 768])
+def test_fp32_index_with_presplit_gallery_is_identical(S, oracle, device, E):
+    """Round 3: a GalleryIndex over an fp32 gallery keeps the gallery's hi / lo bf16 split and its scan
+    streams that instead of splitting every tile again (mmr_gallery_split_bf16 + mmr_cosine_topk_split).  Same split function,
+    same MFMA operands: indices, fp64 dots, scores AND the per-query path status must equal the per-call path and the oracle --
+    ragged last tile, two scan passes (> 128 queries), a crowded boundary that needs the exhaustive path, un-normalised rows."""
+    from mmr_amd import search
+    N = 50003
+    gal = synth.synth_unit_rows(N, E, seed=61) * torch.linspace(0.5, 3.0, N).unsqueeze(1)
+    q = synth.synth_unit_rows(131, E, seed=62)
+    dup = list(range(700, 40700, 1000))
+    v = gal[77] / gal[77].norm() * 3.5                           # the longest row: its 41 copies are query 0's whole top-10
+    gal[77] = v
+    gal[dup] = v.clone()
+    q[0] = v / v.norm()
+    gd, qd = gal.to(device), q.to(device)
+    plain = search.GalleryIndex(gd, presplit=False)
+    split = search.GalleryIndex(gd, presplit=True)
+    assert split._split is not None and plain._split is None
+    a = plain.search(qd, 10, 100.0, return_dot64=True, return_status=True)
+    b = split.search(qd, 10, 100.0, return_dot64=True, return_status=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    oi, os_, od = oracle.cosine_topk(q, gal, 10, scale=100.0)
+    assert np.array_equal(b[1].cpu().numpy(), oi) and np.array_equal(b[2].cpu().numpy(), od)
+    assert np.array_equal(b[0].cpu().numpy(), os_)
+    assert int(b[3][0]) == 1                                      # the crowded query took the exhaustive path in both
+    # in-place row updates go through update_rows: bound and split are both re-measured
+    rows = torch.tensor([5, 4000, N - 1])
+    newv = synth.synth_unit_rows(3, E, seed=63) * 7.0
+    split.update_rows(rows, newv)
+    gal2 = gal.clone()
+    gal2[rows] = newv
+    s2, i2, d2 = split.search(qd, 10, 100.0, return_dot64=True)
+    oi2, os2, od2 = oracle.cosine_topk(q, gal2, 10, scale=100.0)
+    assert np.array_equal(i2.cpu().numpy(), oi2) and np.array_equal(d2.cpu().numpy(), od2)
+    # the packed (sharded-search) message uses the same path
+    assert torch.equal(split.search_packed(qd[:5], 10, 1.0, 1000)[..., 0] - 1000, i2[:5])
+    # bf16 galleries never carry a split
+    assert search.GalleryIndex(gd.bfloat16(), presplit=True)._split is None
