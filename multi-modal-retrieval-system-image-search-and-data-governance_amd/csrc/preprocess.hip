@@ -8,6 +8,8 @@
 // result is bit-identical to Pillow's.  Only the crop window and the input rows it needs are computed.
 #include "mmr_common.h"
 
+#include <stdlib.h>
+
 namespace mmr {
 
 constexpr int PRECISION_BITS = 32 - 8 - 2;   // Pillow Resample.c
@@ -198,13 +200,17 @@ __device__ __forceinline__ void resample_h_fast(const uint8_t *__restrict__ img,
     o[0] = (uint8_t)clip8(a0); o[1] = (uint8_t)clip8(a1); o[2] = (uint8_t)clip8(a2);
 }
 
-// vertical pass + normalise of one image; block = 4 waves, wave w handles output row 4*blockIdx.x + w, lane l the pixels
-// 4l .. 4l+3 of it.  lut: LDS [3][256] of TOUT-rounded ((v/255) - mean[c]) / std[c].
-template <typename TOUT>
+// vertical pass + normalise of one image; block = 4 waves over VR output rows (VR / 4 consecutive ones per wave), lane l the
+// pixels 4l .. 4l+3 of a row.  lut: LDS [3][256] of TOUT-rounded ((v/255) - mean[c]) / std[c] -- two IEEE divisions per
+// entry, about the cost of one output row per wave, hence VR = 8 for batches (4, 16, 32 measured within 5 % of it) (VR = 4 keeps a single image's few
+// workgroups short).  Taps go two at a time (12 byte products + 12 three-operand adds per pair) and the next pair's rows are
+// requested before the current pair is multiplied; the coefficient row is wave-uniform (scalar loads).
+template <typename TOUT, int VR>
 __device__ __forceinline__ void resample_v_fast(const uint8_t *__restrict__ tmp, int S, int row0, const int2 *__restrict__ vb,
                                                 const int *__restrict__ vc, int vk, float m0, float m1, float m2, float s0,
                                                 float s1, float s2, TOUT *__restrict__ out, uint8_t *__restrict__ u8, int yblk)
 {
+    static_assert(VR % 4 == 0, "whole rows per wave");
     __shared__ float lut[3][256];
     for (int i = threadIdx.x; i < 768; i += blockDim.x) {
         const int c = i >> 8, v = i & 255;
@@ -214,45 +220,57 @@ __device__ __forceinline__ void resample_v_fast(const uint8_t *__restrict__ tmp,
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const int y = yblk * 4 + (threadIdx.x >> 6);
-    if (y >= S || lane * 4 >= S) return;
-    const int2 b = vb[y];
-    const int *k = vc + (size_t)y * vk;
-    const uint8_t *p = tmp + ((size_t)(b.x - row0) * S + lane * 4) * 3;
-    int a[12];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (lane * 4 >= S) return;
+    const size_t stride = (size_t)S * 3;
+    for (int j = 0; j < VR / 4; ++j) {
+        const int y = yblk * VR + wave * (VR / 4) + j;
+        if (y >= S) return;
+        const int2 b = vb[y];
+        const int n = b.y;
+        const int *k = vc + (size_t)y * vk;
+        const uint8_t *p = tmp + ((size_t)(b.x - row0) * S + lane * 4) * 3;     // tmp carries 16 bytes of slack behind its last row
+        int a[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) a[i] = 1 << (PRECISION_BITS - 1);
-    for (int t = 0; t < b.y; ++t) {
-        const int kk = k[t];
-        const u32x3 d = load12(p + (size_t)t * S * 3);        // tmp carries 16 bytes of slack behind its last row
+        for (int i = 0; i < 12; ++i) a[i] = 1 << (PRECISION_BITS - 1);
+        if (n > 0) {
+            // rows past the window are read as its last row and weighted 0
+            u32x3 d0 = load12(p), d1 = load12(p + (size_t)min(1, n - 1) * stride);
+            for (int t = 0; t < n; t += 2) {
+                const u32x3 e0 = load12(p + (size_t)min(t + 2, n - 1) * stride);
+                const u32x3 e1 = load12(p + (size_t)min(t + 3, n - 1) * stride);
+                const int k0 = k[t], k1 = t + 1 < n ? k[t + 1] : 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            a[i] += bmul(byte_of(d.x, i), kk);
-            a[4 + i] += bmul(byte_of(d.y, i), kk);
-            a[8 + i] += bmul(byte_of(d.z, i), kk);
+                for (int i = 0; i < 4; ++i) {
+                    a[i] += bmul(byte_of(d0.x, i), k0) + bmul(byte_of(d1.x, i), k1);
+                    a[4 + i] += bmul(byte_of(d0.y, i), k0) + bmul(byte_of(d1.y, i), k1);
+                    a[8 + i] += bmul(byte_of(d0.z, i), k0) + bmul(byte_of(d1.z, i), k1);
+                }
+                d0 = e0; d1 = e1;
+            }
         }
-    }
-    int c[12];
+        int c[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) c[i] = clip8(a[i]);
-    if (u8) {
-        uint32_t w[3];
+        for (int i = 0; i < 12; ++i) c[i] = clip8(a[i]);
+        if (u8) {
+            uint32_t w[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) w[j] = (uint32_t)c[4 * j] | ((uint32_t)c[4 * j + 1] << 8) | ((uint32_t)c[4 * j + 2] << 16) | ((uint32_t)c[4 * j + 3] << 24);
-        uint32_t *o8 = reinterpret_cast<uint32_t *>(u8 + ((size_t)y * S + lane * 4) * 3);     // 12-byte aligned: S % 4 == 0
-        o8[0] = w[0]; o8[1] = w[1]; o8[2] = w[2];
-    }
-    const size_t plane = (size_t)S * S, o = (size_t)y * S + lane * 4;
+            for (int q = 0; q < 3; ++q) w[q] = (uint32_t)c[4 * q] | ((uint32_t)c[4 * q + 1] << 8) | ((uint32_t)c[4 * q + 2] << 16) | ((uint32_t)c[4 * q + 3] << 24);
+            uint32_t *o8 = reinterpret_cast<uint32_t *>(u8 + ((size_t)y * S + lane * 4) * 3);     // 12-byte aligned: S % 4 == 0
+            o8[0] = w[0]; o8[1] = w[1]; o8[2] = w[2];
+        }
+        const size_t plane = (size_t)S * S, o = (size_t)y * S + lane * 4;
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float f0 = lut[ch][c[ch]], f1 = lut[ch][c[3 + ch]], f2 = lut[ch][c[6 + ch]], f3 = lut[ch][c[9 + ch]];
-        if constexpr (sizeof(TOUT) == 2) {
-            uint2 pk;
-            pk.x = pack_bf16x2(f0, f1);
-            pk.y = pack_bf16x2(f2, f3);
-            *reinterpret_cast<uint2 *>((bf16_t *)out + ch * plane + o) = pk;
-        } else {
-            *reinterpret_cast<float4 *>((float *)out + ch * plane + o) = make_float4(f0, f1, f2, f3);
+        for (int ch = 0; ch < 3; ++ch) {
+            const float f0 = lut[ch][c[ch]], f1 = lut[ch][c[3 + ch]], f2 = lut[ch][c[6 + ch]], f3 = lut[ch][c[9 + ch]];
+            if constexpr (sizeof(TOUT) == 2) {
+                uint2 pk;
+                pk.x = pack_bf16x2(f0, f1);
+                pk.y = pack_bf16x2(f2, f3);
+                *reinterpret_cast<uint2 *>((bf16_t *)out + ch * plane + o) = pk;
+            } else {
+                *reinterpret_cast<float4 *>((float *)out + ch * plane + o) = make_float4(f0, f1, f2, f3);
+            }
         }
     }
 }
@@ -264,6 +282,7 @@ __device__ __forceinline__ void resample_v_fast(const uint8_t *__restrict__ tmp,
 // (aligned dword reads + v_alignbyte to the window's byte offset) and the RB finished rows of the intermediate image leave
 // through LDS as whole 16-byte stores: ~1 global instruction per output pixel instead of 9.  Same integer sums, same bytes.
 // LDS: RB * pitch (input rows, pitch = row bytes rounded up to 16, + 32 of slack) + RB * S * 3 (output rows).
+template <int RG>
 __device__ __forceinline__ void resample_h_lds(const uint8_t *__restrict__ img, int H, int W, int S, int row0, int rows,
                                                const int2 *__restrict__ hb, const int *__restrict__ hc, int hk,
                                                uint8_t *__restrict__ tmp, int rblk, int RB, int pitch, char *lds)
@@ -296,27 +315,41 @@ __device__ __forceinline__ void resample_h_lds(const uint8_t *__restrict__ img, 
         *reinterpret_cast<uint4 *>(lin + (size_t)r * pitch + c * 16) = v;
     }
     __syncthreads();
-    // ---- compute: thread -> output column x, all nr rows
-    for (int x = threadIdx.x; x < S; x += blockDim.x) {
+    // ---- compute: item = (column x, group of RG rows).  Tap groups run in the OUTER loop and the RG rows inside it, so a
+    // column's coefficient group is loaded once per RG rows (and one group ahead of its use) and the inner loop is LDS reads and
+    // integer math only; rows past nr compute on stale LDS and are not stored
+    const int nrg = (nr + RG - 1) / RG;
+    for (int it = threadIdx.x; it < S * nrg; it += blockDim.x) {
+        const int rg = it / S, x = it - rg * S, rbase = rg * RG;
         const int2 b = hb[x];
         const int groups = (b.y + 3) >> 2;
         const int4 *k4 = reinterpret_cast<const int4 *>(hc + (size_t)x * hk);
         const int off = b.x * 3, a = off & ~3, sh = off & 3;
-        for (int r = 0; r < nr; ++r) {
-            const uint32_t *w = reinterpret_cast<const uint32_t *>(lin + (size_t)r * pitch + a);
-            int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
-            uint32_t prev = w[0];
-            for (int g = 0; g < groups; ++g) {
-                const uint32_t w1 = w[3 * g + 1], w2 = w[3 * g + 2], w3 = w[3 * g + 3];
+        const uint8_t *base = lin + (size_t)rbase * pitch + a;
+        int acc[RG][3];
+#pragma unroll
+        for (int r = 0; r < RG; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 1 << (PRECISION_BITS - 1);
+        int4 k = k4[0];
+        for (int g = 0; g < groups; ++g) {
+            const int4 kn = k4[g + 1 < groups ? g + 1 : g];
+#pragma unroll
+            for (int r = 0; r < RG; ++r) {
+                const uint32_t *w = reinterpret_cast<const uint32_t *>(base + (size_t)r * pitch) + 3 * g;
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
                 u32x3 d;                                         // the 12 window bytes of this tap group, realigned
-                d.x = __builtin_amdgcn_alignbyte(w1, prev, sh);
+                d.x = __builtin_amdgcn_alignbyte(w1, w0, sh);
                 d.y = __builtin_amdgcn_alignbyte(w2, w1, sh);
                 d.z = __builtin_amdgcn_alignbyte(w3, w2, sh);
-                prev = w3;
-                mac4taps(d, k4[g], a0, a1, a2);
+                mac4taps(d, k, acc[r][0], acc[r][1], acc[r][2]);
             }
-            uint8_t *o = lout + ((size_t)r * S + x) * 3;
-            o[0] = (uint8_t)clip8(a0); o[1] = (uint8_t)clip8(a1); o[2] = (uint8_t)clip8(a2);
+            k = kn;
+        }
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            if (rbase + r < nr) {
+                uint8_t *o = lout + ((size_t)(rbase + r) * S + x) * 3;
+                o[0] = (uint8_t)clip8(acc[r][0]); o[1] = (uint8_t)clip8(acc[r][1]); o[2] = (uint8_t)clip8(acc[r][2]);
+            }
         }
     }
     __syncthreads();
@@ -341,22 +374,24 @@ __device__ __forceinline__ void resample_h_lds(const uint8_t *__restrict__ img, 
     for (int i = head + body * 16 + threadIdx.x; i < total; i += blockDim.x) dst[i] = lout[i];
 }
 
-__global__ __launch_bounds__(256) void resample_h_lds_kernel(const uint8_t *__restrict__ img, int H, int W, int S, int row0,
+template <int RG>
+__global__ __launch_bounds__(512) void resample_h_lds_kernel(const uint8_t *__restrict__ img, int H, int W, int S, int row0,
                                                              int rows, const int2 *__restrict__ hb, const int *__restrict__ hc,
                                                              int hk, uint8_t *__restrict__ tmp, int RB, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) char pre_lds[];
-    resample_h_lds(img, H, W, S, row0, rows, hb, hc, hk, tmp, blockIdx.x, RB, pitch, pre_lds);
+    resample_h_lds<RG>(img, H, W, S, row0, rows, hb, hc, hk, tmp, blockIdx.x, RB, pitch, pre_lds);
 }
 
 // batched: RB / pitch are sized on the host for the WIDEST image of the batch (max_w); an image whose tables are not in
 // the padded layout takes the byte-wise path inside the same launch (thread id -> (row, column) of this row block)
-__global__ __launch_bounds__(256) void resample_h_lds_batch_kernel(const PreDesc *__restrict__ desc, int S, int RB, int pitch)
+template <int RG>
+__global__ __launch_bounds__(512) void resample_h_lds_batch_kernel(const PreDesc *__restrict__ desc, int S, int RB, int pitch)
 {
     extern __shared__ __attribute__((aligned(16))) char pre_lds[];
     const PreDesc d = desc[blockIdx.y];
     if ((d.hk & 3) == 0 && ((uintptr_t)d.hcoeffs & 15) == 0 && d.W * 3 + 32 <= pitch) {
-        resample_h_lds(d.img, d.H, d.W, S, d.row0, d.rows, reinterpret_cast<const int2 *>(d.hbounds), d.hcoeffs, d.hk, d.tmp,
+        resample_h_lds<RG>(d.img, d.H, d.W, S, d.row0, d.rows, reinterpret_cast<const int2 *>(d.hbounds), d.hcoeffs, d.hk, d.tmp,
                        blockIdx.x, RB, pitch, pre_lds);
         return;
     }
@@ -383,13 +418,17 @@ __global__ __launch_bounds__(256) void resample_h_fast_kernel(const uint8_t *__r
     resample_h_fast(img, H, W, S, row0, rows, hb, hc, hk, tmp, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+#ifndef MMR_V_ROWS_BATCH
+#define MMR_V_ROWS_BATCH 8
+#endif
+constexpr int V_ROWS_IMAGE = 4, V_ROWS_BATCH = MMR_V_ROWS_BATCH;
 template <typename TOUT>
 __global__ __launch_bounds__(256) void resample_v_fast_kernel(const uint8_t *__restrict__ tmp, int S, int row0,
                                                               const int2 *__restrict__ vb, const int *__restrict__ vc, int vk,
                                                               float m0, float m1, float m2, float s0, float s1, float s2,
                                                               TOUT *__restrict__ out, uint8_t *__restrict__ u8)
 {
-    resample_v_fast<TOUT>(tmp, S, row0, vb, vc, vk, m0, m1, m2, s0, s1, s2, out, u8, blockIdx.x);
+    resample_v_fast<TOUT, V_ROWS_IMAGE>(tmp, S, row0, vb, vc, vk, m0, m1, m2, s0, s1, s2, out, u8, blockIdx.x);
 }
 
 // per image: the 12-byte form when its coefficient rows are padded to whole groups of 4 taps and 16-byte aligned (what
@@ -421,7 +460,7 @@ __global__ __launch_bounds__(256) void resample_v_fast_batch_kernel(const PreDes
                                                                     float m2, float s0, float s1, float s2, TOUT *__restrict__ out)
 {
     const PreDesc d = desc[blockIdx.y];
-    resample_v_fast<TOUT>(d.tmp, S, d.row0, reinterpret_cast<const int2 *>(d.vbounds), d.vcoeffs, d.vk, m0, m1, m2, s0, s1, s2,
+    resample_v_fast<TOUT, V_ROWS_BATCH>(d.tmp, S, d.row0, reinterpret_cast<const int2 *>(d.vbounds), d.vcoeffs, d.vk, m0, m1, m2, s0, s1, s2,
                           out + (size_t)blockIdx.y * 3 * S * S, nullptr, blockIdx.x);
 }
 
@@ -429,14 +468,50 @@ __global__ __launch_bounds__(256) void resample_v_fast_batch_kernel(const PreDes
 
 using namespace mmr;
 
-// LDS plan of the staged horizontal pass for images up to `width` pixels wide: rows per workgroup and row pitch; RB = 0 when
-// even one row does not fit the 64 KiB the pass allows itself (two workgroups per CU)
-static void plan_h_lds(int width, int S, int &RB, int &pitch)
+// LDS plan of the staged horizontal pass for images up to `width` pixels wide: rows per workgroup (RB), rows per thread
+// (RG, a template parameter: RB is a multiple of it), row pitch and workgroup size (one thread per (column, row group),
+// whole waves, at most 512); RB = 0 when even one row does not fit the 64 KiB the pass allows itself (two workgroups per CU)
+struct HPlan { int RB, RG, pitch, threads; };
+static HPlan plan_h_lds(int width, int S)
 {
-    pitch = (int)align_up((size_t)width * 3, 16) + 32;
-    const int per_row = pitch + S * 3;
-    RB = width > 0 ? (64 * 1024) / per_row : 0;
-    if (RB > 8) RB = 8;
+    HPlan p;
+    p.pitch = (int)align_up((size_t)width * 3, 16) + 32;
+    const int per_row = p.pitch + S * 3;
+    p.RB = width > 0 ? (64 * 1024) / per_row : 0;
+    static const int rb_cap = getenv("MMR_PRE_RB") ? atoi(getenv("MMR_PRE_RB")) : 8;      // A/B aids
+    static const int rg_env = getenv("MMR_PRE_RG") ? atoi(getenv("MMR_PRE_RG")) : 8;
+    if (p.RB > rb_cap) p.RB = rb_cap;
+    p.RG = (p.RB >= 8 && rg_env >= 8) ? 8 : (p.RB >= 4 && rg_env >= 4 ? 4 : 1);
+    p.RB -= p.RB % p.RG;
+    const long items = (long)S * (p.RB / (p.RG ? p.RG : 1));
+    p.threads = (int)(items >= 512 ? 512 : (items <= 64 ? 64 : align_up((size_t)items, 64)));
+    return p;
+}
+
+template <int RG>
+static int launch_h_lds_batch(const PreDesc *d, int B, int S, int max_rows, const HPlan &p, hipStream_t st)
+{
+    static DeviceOnce once;
+    if (once.first())
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_h_lds_batch_kernel<RG>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    hipLaunchKernelGGL(resample_h_lds_batch_kernel<RG>, dim3((max_rows + p.RB - 1) / p.RB, B), dim3(p.threads),
+                       (size_t)p.RB * (p.pitch + S * 3), st, d, S, p.RB, p.pitch);
+    return MMR_OK;
+}
+
+template <int RG>
+static int launch_h_lds(const uint8_t *img, int H, int W, int S, int row0, int rows, const int32_t *hbounds,
+                        const int32_t *hcoeffs, int hk, uint8_t *tmp, const HPlan &p, hipStream_t st)
+{
+    static DeviceOnce once;
+    if (once.first())
+        MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_h_lds_kernel<RG>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    hipLaunchKernelGGL(resample_h_lds_kernel<RG>, dim3((rows + p.RB - 1) / p.RB), dim3(p.threads),
+                       (size_t)p.RB * (p.pitch + S * 3), st, img, H, W, S, row0, rows, (const int2 *)hbounds, hcoeffs, hk, tmp,
+                       p.RB, p.pitch);
+    return MMR_OK;
 }
 
 extern "C" int mmr_preprocess_batch(const void *desc, int B, int S, int max_rows, float mean0, float mean1, float mean2,
@@ -458,21 +533,18 @@ extern "C" int mmr_preprocess_batch_ex(const void *desc, int B, int S, int max_r
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(MMR_PROF_ROWWISE, st);
     const PreDesc *d = (const PreDesc *)desc;
-    int RB = 0, pitch = 0;
-    plan_h_lds(max_width, S, RB, pitch);
-    if (RB >= 1) {                        // input rows staged in LDS (max_width = the widest image of the batch)
-        const size_t lds = (size_t)RB * (pitch + S * 3);
-        static DeviceOnce once;
-        if (once.first())
-            MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_h_lds_batch_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        hipLaunchKernelGGL(resample_h_lds_batch_kernel, dim3((max_rows + RB - 1) / RB, B), dim3(256), lds, st, d, S, RB, pitch);
+    const HPlan hp = plan_h_lds(max_width, S);
+    if (hp.RB >= 1) {                     // input rows staged in LDS (max_width = the widest image of the batch)
+        const int rc = hp.RG == 8 ? launch_h_lds_batch<8>(d, B, S, max_rows, hp, st)
+                     : hp.RG == 4 ? launch_h_lds_batch<4>(d, B, S, max_rows, hp, st)
+                                  : launch_h_lds_batch<1>(d, B, S, max_rows, hp, st);
+        if (rc != MMR_OK) return rc;
     } else {
         hipLaunchKernelGGL(resample_h_fast_batch_kernel, dim3(((size_t)max_rows * S + 255) / 256, B), dim3(256), 0, st, d, S);
     }
     MMR_CHECK_LAUNCH();
-    if (S % 4 == 0) {                     // 4 pixels per lane, one wave per output row
-        const dim3 grid((S + 3) / 4, B);
+    if (S % 4 == 0) {                     // 4 pixels per lane, V_ROWS_BATCH output rows per workgroup
+        const dim3 grid((S + V_ROWS_BATCH - 1) / V_ROWS_BATCH, B);
         if (out_dtype == MMR_BF16)
             hipLaunchKernelGGL(resample_v_fast_batch_kernel<bf16_t>, grid, dim3(256), 0, st, d, S, mean0, mean1, mean2, std0, std1,
                                std2, (bf16_t *)out);
@@ -502,15 +574,12 @@ extern "C" int mmr_preprocess_image(const uint8_t *img, int H, int W, int S, int
     MMR_CHECK_ARG(std0 != 0.f && std1 != 0.f && std2 != 0.f, "mmr_preprocess_image: zero std");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(MMR_PROF_ROWWISE, st);
-    int RB = 0, pitch = 0;
-    plan_h_lds(W, S, RB, pitch);
-    if (hk % 4 == 0 && ((uintptr_t)hcoeffs & 15) == 0 && RB >= 1) {
-        static DeviceOnce once;
-        if (once.first())
-            MMR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&resample_h_lds_kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        hipLaunchKernelGGL(resample_h_lds_kernel, dim3((rows + RB - 1) / RB), dim3(256), (size_t)RB * (pitch + S * 3), st, img, H, W,
-                           S, row0, rows, (const int2 *)hbounds, hcoeffs, hk, tmp, RB, pitch);
+    const HPlan hp = plan_h_lds(W, S);
+    if (hk % 4 == 0 && ((uintptr_t)hcoeffs & 15) == 0 && hp.RB >= 1) {
+        const int rc = hp.RG == 8 ? launch_h_lds<8>(img, H, W, S, row0, rows, hbounds, hcoeffs, hk, tmp, hp, st)
+                     : hp.RG == 4 ? launch_h_lds<4>(img, H, W, S, row0, rows, hbounds, hcoeffs, hk, tmp, hp, st)
+                                  : launch_h_lds<1>(img, H, W, S, row0, rows, hbounds, hcoeffs, hk, tmp, hp, st);
+        if (rc != MMR_OK) return rc;
     } else if (hk % 4 == 0 && ((uintptr_t)hcoeffs & 15) == 0)
         hipLaunchKernelGGL(resample_h_fast_kernel, dim3((rows * S + 255) / 256), dim3(256), 0, st, img, H, W, S, row0, rows,
                            (const int2 *)hbounds, hcoeffs, hk, tmp);
@@ -520,10 +589,10 @@ extern "C" int mmr_preprocess_image(const uint8_t *img, int H, int W, int S, int
     MMR_CHECK_LAUNCH();
     if (S % 4 == 0) {
         if (out_dtype == MMR_BF16)
-            hipLaunchKernelGGL(resample_v_fast_kernel<bf16_t>, dim3((S + 3) / 4), dim3(256), 0, st, tmp, S, row0,
+            hipLaunchKernelGGL(resample_v_fast_kernel<bf16_t>, dim3((S + V_ROWS_IMAGE - 1) / V_ROWS_IMAGE), dim3(256), 0, st, tmp, S, row0,
                                (const int2 *)vbounds, vcoeffs, vk, mean0, mean1, mean2, std0, std1, std2, (bf16_t *)out, out_u8);
         else
-            hipLaunchKernelGGL(resample_v_fast_kernel<float>, dim3((S + 3) / 4), dim3(256), 0, st, tmp, S, row0,
+            hipLaunchKernelGGL(resample_v_fast_kernel<float>, dim3((S + V_ROWS_IMAGE - 1) / V_ROWS_IMAGE), dim3(256), 0, st, tmp, S, row0,
                                (const int2 *)vbounds, vcoeffs, vk, mean0, mean1, mean2, std0, std1, std2, (float *)out, out_u8);
         MMR_CHECK_LAUNCH();
         return MMR_OK;

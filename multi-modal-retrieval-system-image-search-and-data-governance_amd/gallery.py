@@ -83,7 +83,7 @@ def build_gallery_overlapped(model, raw_batches: Iterable[torch.Tensor], total: 
 
     Two schedules, bit-identical results (tested):
       * ``overlap=False`` (default): both stages back to back on the caller's stream.  Measured on MI355X (ViT-B/32, 256 VGA
-        images per batch): 0.93 of the encode-only rate -- the preprocess costs 0.19 ms of the 3.2 ms step.
+        images per batch): 0.936 of the encode-only rate -- the preprocess costs 0.15 ms of the 3.1 ms step.
       * ``overlap=True``: batch i+1 is preprocessed on a low-priority side stream while batch i is encoded.  Measured SLOWER
         (0.77 of encode-only, whatever the stream priority): the encoder's GEMMs are one 160 KiB-LDS workgroup per CU, and a
         CU that holds preprocess workgroups cannot take one, so the persistent tile schedules start ragged.  Kept because it
