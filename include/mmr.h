@@ -78,15 +78,22 @@ int mmr_cosine_topk_ex(const void *q, const void *gallery, mmr_dtype dtype, int 
                        void *stream);
 
 /* fp32 galleries that are searched many times: split the gallery ONCE into hi = bf16(x) and lo = bf16(x - hi) (two bf16
- * arrays [N,E], together the bytes of the fp32 gallery), then search with mmr_cosine_topk_split -- the scan streams the two
- * arrays and skips the per-tile split mmr_cosine_topk performs on fp32 rows (1M x 512 x 128 queries: 0.60 -> see DESIGN.md);
- * the exact fp64 re-score still reads the fp32 gallery, so results are IDENTICAL to mmr_cosine_topk_ex(..., MMR_F32, ...).
- * The split arrays must come from mmr_gallery_split_bf16 of the SAME gallery contents. */
-int mmr_gallery_split_bf16(const float *gallery, int64_t N, int E, void *hi, void *lo, void *stream);
-int mmr_cosine_topk_split(const void *q, const void *gallery, const void *gallery_hi, const void *gallery_lo, int Q,
-                          int64_t N, int E, int k, float scale, float gallery_norm_bound, const float *gallery_norm_bound_dev,
-                          int32_t *idx, float *score, double *dot64, int32_t *status, void *workspace, size_t workspace_bytes,
-                          void *stream);
+ * arrays [N,E], together the bytes of the fp32 gallery), then search with mmr_cosine_topk_split.  That search runs in tiers:
+ *   1. the bf16 scan over `hi` alone with bf16-rounded queries (half the gallery bytes, one MFMA product), certified with a
+ *      margin that adds the measured rounding residuals |q - bf16(q)| * max|g| + |q| * max_row|g - hi| and 32 candidate tiles;
+ *   2. only for queries tier 1 leaves open: the three-product scan q_hi.g_hi + q_lo.g_hi + q_hi.g_lo over hi and lo (the scan
+ *      mmr_cosine_topk runs on fp32 rows, minus its per-tile split) with the 8e-5 |q||g| margin;
+ *   3. the exhaustive fp64 path for what is still open.
+ * Every tier ranks on exact fp64 re-scores of the fp32 rows, so idx / score / dot64 are IDENTICAL to
+ * mmr_cosine_topk_ex(..., MMR_F32, ...); status is 0 for tiers 1-2 and 1 for tier 3.
+ * mmr_gallery_split_bf16 also writes max_row ||g - hi||_2 to *resid_bound_out (device float, may be NULL); pass that pointer as
+ * split_resid_bound_dev (NULL = the worst case 2^-8 * norm bound is assumed).  The split arrays and the bound must come from
+ * mmr_gallery_split_bf16 of the SAME gallery contents.  Workspace: mmr_search_workspace_bytes. */
+int mmr_gallery_split_bf16(const float *gallery, int64_t N, int E, void *hi, void *lo, float *resid_bound_out, void *stream);
+int mmr_cosine_topk_split(const void *q, const void *gallery, const void *gallery_hi, const void *gallery_lo,
+                          const float *split_resid_bound_dev, int Q, int64_t N, int E, int k, float scale,
+                          float gallery_norm_bound, const float *gallery_norm_bound_dev, int32_t *idx, float *score,
+                          double *dot64, int32_t *status, void *workspace, size_t workspace_bytes, void *stream);
 
 /* out[Q,N] (fp32) = (float)(dot64 * scale): the materialised score matrix for small N. */
 int mmr_similarity(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, float scale,

@@ -56,9 +56,9 @@ def lib():
     L.mmr_cosine_topk_ex.restype = i32
     L.mmr_cosine_topk_ex.argtypes = [vp, vp, i32, i32, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.mmr_gallery_split_bf16.restype = i32
-    L.mmr_gallery_split_bf16.argtypes = [vp, i64, i32, vp, vp, vp]
+    L.mmr_gallery_split_bf16.argtypes = [vp, i64, i32, vp, vp, vp, vp]
     L.mmr_cosine_topk_split.restype = i32
-    L.mmr_cosine_topk_split.argtypes = [vp, vp, vp, vp, i32, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, sz, vp]
+    L.mmr_cosine_topk_split.argtypes = [vp, vp, vp, vp, vp, i32, i64, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, sz, vp]
     L.mmr_gallery_norm_bound.restype = i32
     L.mmr_gallery_norm_bound.argtypes = [vp, i32, i64, i32, vp, vp]
     L.mmr_similarity.restype = i32

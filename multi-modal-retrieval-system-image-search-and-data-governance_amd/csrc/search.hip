@@ -476,11 +476,12 @@ __global__ __launch_bounds__(ScanF32Cfg<E>::SCAN_THREADS, ScanF32Cfg<E>::SCAN_WA
 
 // ---------------------------------------------------------------------------------------------
 // scan for fp32 galleries at the bf16 MFMA rate: split-bf16.  Every fp32 value x is split into hi = bf16(x) and
-// lo = bf16(x - hi) (x = hi + lo up to 2^-18 |x|) and the dot product is accumulated as q_hi.g_hi + q_lo.g_hi + q_hi.g_lo
-// on v_mfma_f32_16x16x32_bf16 -- three MFMAs per 32-deep k-step instead of the eight v_mfma_f32_16x16x4_f32 (1/16 of the
-// bf16 rate) scan_f32_kernel needs.  Error of the approximate dot against the exact one: dropped q_lo.g_lo and the two
-// representation residuals, 3 * 2^-18 |q||g| = 1.1e-5, plus fp32 accumulation ~5e-6: well inside the certificate's
-// 8e-5 |q||g| margin, and the ranking itself is still done on exact fp64 re-scores.
+// lo = bf16(x - hi) (bf16 keeps 8 significand bits: |x - hi| <= 2^-8 |x|, so x = hi + lo up to 2^-16 |x|) and the dot product
+// is accumulated as q_hi.g_hi + q_lo.g_hi + q_hi.g_lo on v_mfma_f32_16x16x32_bf16 -- three MFMAs per 32-deep k-step instead of
+// the eight v_mfma_f32_16x16x4_f32 (1/16 of the bf16 rate) scan_f32_kernel needs.  Error of the approximate dot against the
+// exact one: the dropped q_lo.g_lo and the two representation residuals, 3 * 2^-16 |q||g| = 4.6e-5 in the worst case (1e-5
+// typical), plus fp32 accumulation (a 32-term tree per MFMA, then E/32 chained adds: <= ~30 * 2^-24 = 2e-6): inside the
+// certificate's 8e-5 |q||g| margin, and the ranking itself is still done on exact fp64 re-scores.
 // Per 16-row tile: the fp32 rows arrive by global_load_lds (ring of NBUF tiles); ALL waves then split the tile ONCE into
 // two bf16 images (hi, lo; 24 VALU instructions per 8 values -- done per consuming wave instead, the conversion was 8x
 // redundant and the kernel VALU-bound: 0.78 ms for 1M x 512 x 128 queries); the computing waves read their A fragments
@@ -702,12 +703,44 @@ __global__ __launch_bounds__(256) void split_gallery_kernel(const float *__restr
     *reinterpret_cast<bf16x8 *>(lo + i * 8) = l;
 }
 
+// fp32 queries rounded to bf16 (nearest-even, the gallery split's hi): operands of the first-tier scan.  One wave per query;
+// qres[query] = ||q - bf16(q)||_2, rounded up: the query half of that tier's certificate margin.
+__global__ __launch_bounds__(256) void queries_to_bf16_kernel(const float *__restrict__ q, int Q, int E, bf16_t *__restrict__ out,
+                                                              float *__restrict__ qres)
+{
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= Q) return;
+    const float *p = q + (size_t)row * E;
+    float ss = 0.f;
+    for (int c = lane; c < E / 8; c += 64) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(p + c * 8), a1 = *reinterpret_cast<const float4 *>(p + c * 8 + 4);
+        const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        union { bf16x8 v; uint32_t u[4]; } h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            h.u[j] = pack_bf16x2(x[2 * j], x[2 * j + 1]);
+            const float r0 = x[2 * j] - __uint_as_float(h.u[j] << 16);            // exact: the residual of a rounding
+            const float r1 = x[2 * j + 1] - __uint_as_float(h.u[j] & 0xffff0000u);
+            ss += r0 * r0 + r1 * r1;
+        }
+        *reinterpret_cast<bf16x8 *>(out + (size_t)row * E + c * 8) = h.v;
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) qres[row] = sqrtf(ss) * 1.00001f;
+}
+
 template <int E>
 __global__ __launch_bounds__(ScanF32sCfg<E>::SCAN_THREADS, ScanF32sCfg<E>::SCAN_WAVES / 4) void scan_split_kernel(
     const float *__restrict__ q, const bf16_t *__restrict__ ghi, const bf16_t *__restrict__ glo, int Q, int64_t N, int ntiles,
-    int tpt, int qwaves, int qpad, float *__restrict__ bmax, float *__restrict__ tmax)
+    int tpt, int qwaves, int qpad, float *__restrict__ bmax, float *__restrict__ tmax, const int32_t *__restrict__ gate)
 {
     using C = ScanF32sCfg<E>;
+    if (gate) {                              // second tier: nothing to do unless the first tier left one of these queries open
+        int open = 0;
+        for (int i = threadIdx.x; i < Q; i += blockDim.x) open |= gate[i];
+        if (!__syncthreads_or(open)) return;
+    }
     constexpr int SNBUF = C::NBUF;          // a fourth ring slot and fragment reads six k-steps ahead both measured no faster
     static_assert(2 * C::IMG_BYTES == C::TILE_BYTES, "a ring slot holds the hi and the lo image of one 16-row tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1285,13 +1318,15 @@ struct FinMeta { float bound; float qnorm; };   // per query: best excluded appr
 
 __global__ __launch_bounds__(FIN_THREADS) void select_kernel(
     int ks, int ntiles, int tpt, int ntasks, int qpad, const float *__restrict__ bmax,
-    const float *__restrict__ tmax, int32_t *__restrict__ sel_tiles /*[Q][KS_MAX]*/, FinMeta *__restrict__ meta)
+    const float *__restrict__ tmax, int32_t *__restrict__ sel_tiles /*[Q][KS_MAX]*/, FinMeta *__restrict__ meta,
+    const int32_t *__restrict__ gate)
 {
     __shared__ SelScratch<float> scf;
     __shared__ float sel_v[KS_MAX + 1];
     __shared__ int32_t sel_task[KS_MAX + 1];
     __shared__ int32_t sel_tile[KS_MAX + 1];
     const int qi = blockIdx.x, tid = threadIdx.x;
+    if (gate && gate[qi] == 0) return;          // second tier of the fp32 search: only queries the first tier left open
 
     // level 1: best ks tasks (+1 to learn the best excluded one)
     wg_select<float>(ntasks, ks + 1, [&](int i, float &v, int32_t &key) {
@@ -1315,10 +1350,12 @@ __global__ __launch_bounds__(FIN_THREADS) void select_kernel(
 template <typename T, int PER>
 __global__ __launch_bounds__(FIN_THREADS) void rescore_kernel(
     const T *__restrict__ q, const T *__restrict__ gal, int64_t N, int tile_rows,
-    const int32_t *__restrict__ sel_tiles, double *__restrict__ cand /*[Q][KS_MAX*32]*/, FinMeta *__restrict__ meta)
+    const int32_t *__restrict__ sel_tiles, double *__restrict__ cand /*[Q][KS_MAX*32]*/, FinMeta *__restrict__ meta,
+    const int32_t *__restrict__ gate)
 {
     constexpr int E = PER * 64;
     const int slot = blockIdx.x, qi = blockIdx.y;
+    if (gate && gate[qi] == 0) return;
     const int tid = threadIdx.x, lane = tid & 63, m = lane & 15, grp = tid >> 4;   // 16 row groups
     const int32_t tile = sel_tiles[(size_t)qi * KS_MAX + slot];
     QuadQuery<T, PER> qq;
@@ -1352,12 +1389,14 @@ __global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
     const FinMeta *__restrict__ meta, float scale, float eps_rel, float host_bound,
     const float *__restrict__ dev_bound, int32_t *__restrict__ idx,
     float *__restrict__ score, double *__restrict__ dot64, int32_t *__restrict__ status,
-    int32_t *__restrict__ need_exact)
+    int32_t *__restrict__ need_exact, const int32_t *__restrict__ gate, const float *__restrict__ qres,
+    const float *__restrict__ gres_dev, float gres_rel)
 {
     __shared__ SelScratch<double> scd;
     __shared__ double out_v[K_MAX];
     __shared__ int32_t out_k[K_MAX];
     const int qi = blockIdx.x, tid = threadIdx.x;
+    if (gate && gate[qi] == 0) return;          // (gate aliases need_exact: this workgroup is its only writer)
     const int32_t *st = sel_tiles + (size_t)qi * KS_MAX;
     const double *cs = cand + (size_t)qi * KS_MAX * TILE_ROWS;
     // candidate i = (slot i / tile_rows, row-in-tile i % tile_rows); cand keeps a 32-entry stride per slot
@@ -1384,7 +1423,14 @@ __global__ __launch_bounds__(FIN_THREADS) void rank_kernel(
         const double bound = (double)meta[qi].bound;
         float gnorm = host_bound;
         if (dev_bound) gnorm = fmaxf(gnorm, *dev_bound);
-        const double eps = (double)eps_rel * (double)gnorm * (double)meta[qi].qnorm;
+        double eps = (double)eps_rel * (double)gnorm * (double)meta[qi].qnorm;
+        if (qres) {
+            // first tier of the split fp32 search: the scan multiplied bf16(q) with hi(g).
+            // |q.g - qh.gh| <= |q - qh| |g| + |qh| |g - gh|, with |q - qh| measured per query, |g - gh| <= the measured maximum
+            // over the gallery's rows (or gres_rel * the norm bound when the caller has none) and |qh| <= (1 + 2^-8) |q|
+            const double gres = gres_dev ? (double)*gres_dev : (double)gres_rel * (double)gnorm;
+            eps += (double)qres[qi] * (double)gnorm + (double)meta[qi].qnorm * (1.0 + 0x1p-8) * gres;
+        }
         const int kk = (int)(N < k ? N : k);
         const bool ok = (bound == -INFINITY) || (out_k[kk - 1] != KEY_NONE && out_v[kk - 1] > bound + eps);
         need_exact[qi] = ok ? 0 : 1;
@@ -1603,6 +1649,30 @@ __global__ __launch_bounds__(256) void rownorm_max_kernel(const T *__restrict__ 
     if (lane == 0) atomicMax(out_bits, __float_as_uint(sqrtf(mx) * 1.000001f));
 }
 
+// Largest row norm of (gallery - hi): the gallery half of the first-tier margin of the split fp32 search.  Same shape as
+// rownorm_max_kernel; the differences are exact fp32 values (residuals of a rounding).
+__global__ __launch_bounds__(256) void split_resid_max_kernel(const float *__restrict__ gal, const bf16_t *__restrict__ hi, int64_t N,
+                                                              int E, unsigned int *__restrict__ out_bits)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float mx = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < N; r += (int64_t)gridDim.x * 4) {
+        const float *p = gal + (size_t)r * E;
+        const bf16_t *ph = hi + (size_t)r * E;
+        float ss = 0.f;
+        for (int c = lane; c < E / 8; c += 64) {
+            const float4 a0 = *reinterpret_cast<const float4 *>(p + c * 8), a1 = *reinterpret_cast<const float4 *>(p + c * 8 + 4);
+            const bf16x8 h = *reinterpret_cast<const bf16x8 *>(ph + c * 8);
+            const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = x[j] - bf16_to_f32((bf16_t)h[j]); ss += d * d; }
+        }
+        ss = wave_sum(ss);
+        mx = fmaxf(mx, ss);
+    }
+    if (lane == 0) atomicMax(out_bits, __float_as_uint(sqrtf(mx) * 1.00001f));
+}
+
 __global__ void fill_empty_kernel(int32_t *idx, float *score, double *dot64, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1682,7 +1752,7 @@ struct SearchPlan {
     int ntiles, tpt, ntasks, nslab, ks, tile_rows, qmax;
     int64_t rows_per_slab;
     bool fast;  // MFMA scan usable
-    size_t off_bmax, off_tmax, off_flags, off_partial, off_seltiles, off_cand, off_meta, off_nb, total;
+    size_t off_bmax, off_tmax, off_flags, off_partial, off_seltiles, off_cand, off_meta, off_nb, off_qb, off_qres, total;
 };
 
 static bool scan_supports_E(int E) { return E == 128 || E == 256 || E == 512 || E == 768; }
@@ -1715,9 +1785,13 @@ static SearchPlan make_plan(int64_t N, int E, int Q, int k, mmr_dtype dt)
     p.rows_per_slab = (N + p.nslab - 1) / p.nslab;
     const int qc = Q < p.qmax ? (Q + 31) / 32 * 32 : p.qmax;
     size_t off = 0;
+    // regions sized by Q and E alone come first: the tiered fp32 search runs a bf16-plan pass and an fp32-plan pass over one
+    // workspace, and both must find the flags and the bf16 copy of the queries at the same place
+    p.off_flags = off; off += align_up((size_t)(Q > 0 ? Q : 1) * sizeof(int32_t), 256);
+    p.off_qb = off; off += align_up((size_t)(Q > 0 ? Q : 1) * E * sizeof(bf16_t), 256);
+    p.off_qres = off; off += align_up((size_t)(Q > 0 ? Q : 1) * sizeof(float), 256);
     p.off_bmax = off; off += align_up((size_t)p.ntiles * qc * sizeof(float), 256);
     p.off_tmax = off; off += align_up((size_t)p.ntasks * qc * sizeof(float), 256);
-    p.off_flags = off; off += align_up((size_t)(Q > 0 ? Q : 1) * sizeof(int32_t), 256);
     p.off_partial = off; off += align_up((size_t)(Q > 0 ? Q : 1) * p.nslab * K_MAX * sizeof(ExhEntry), 256);
     p.off_seltiles = off; off += align_up((size_t)qc * KS_MAX * sizeof(int32_t), 256);
     p.off_cand = off; off += align_up((size_t)qc * KS_MAX * TILE_ROWS * sizeof(double), 256);
@@ -1802,7 +1876,7 @@ static int launch_scan_f32s(const float *q, const float *gal, int Qc, int64_t N,
 
 template <int E>
 static int launch_scan_split(const float *q, const bf16_t *ghi, const bf16_t *glo, int Qc, int64_t N, const SearchPlan &p, int qpad,
-                             float *bmax, float *tmax, hipStream_t st)
+                             float *bmax, float *tmax, hipStream_t st, const int32_t *gate = nullptr)
 {
     ProfScope prof(MMR_PROF_SCAN, st);
     using C = ScanF32sCfg<E>;
@@ -1813,9 +1887,26 @@ static int launch_scan_split(const float *q, const bf16_t *ghi, const bf16_t *gl
                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     }
     hipLaunchKernelGGL(scan_split_kernel<E>, dim3(p.ntasks), dim3(C::SCAN_THREADS), lds, st, q, ghi, glo, Qc, N, p.ntiles, p.tpt,
-                       qpad / 16, qpad, bmax, tmax);
+                       qpad / 16, qpad, bmax, tmax, gate);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
+}
+
+// bf16 scan of one query chunk (the E = 768 form is a run-time choice)
+static int launch_scan_bf16(int E, const bf16_t *q, const bf16_t *gal, int Qc, int64_t N, const SearchPlan &p, int qpad,
+                            float *bmax, float *tmax, hipStream_t st)
+{
+    switch (E) {
+        case 128: return launch_scan<128>(q, gal, Qc, N, p, qpad, bmax, tmax, st);
+        case 256: return launch_scan<256>(q, gal, Qc, N, p, qpad, bmax, tmax, st);
+        case 512: return launch_scan<512>(q, gal, Qc, N, p, qpad, bmax, tmax, st);
+        default: {
+            // MMR_SCAN768=32 keeps the one-wave-per-SIMD 32x32 form for A/B comparisons
+            static const int form = getenv("MMR_SCAN768") ? atoi(getenv("MMR_SCAN768")) : 16;
+            return form == 32 ? launch_scan<768>(q, gal, Qc, N, p, qpad, bmax, tmax, st)
+                              : launch_scan16<768>(q, gal, Qc, N, p, qpad, bmax, tmax, st);
+        }
+    }
 }
 
 template <typename T, int PER>
@@ -1823,18 +1914,19 @@ static int launch_finalize(const T *q, const T *gal, int Qc, int64_t N, int k, c
                            const float *bmax, const float *tmax, float scale, float eps_rel, float host_bound,
                            const float *dev_bound, int32_t *idx,
                            float *score, double *dot64, int32_t *status, int32_t *flags, int32_t *sel_tiles,
-                           double *cand, FinMeta *meta, hipStream_t st)
+                           double *cand, FinMeta *meta, hipStream_t st, const int32_t *gate = nullptr,
+                           const float *qres = nullptr, const float *gres_dev = nullptr, float gres_rel = 0.f)
 {
     ProfScope prof(MMR_PROF_FINALIZE, st);
     hipLaunchKernelGGL(select_kernel, dim3(Qc), dim3(FIN_THREADS), 0, st, p.ks, p.ntiles, p.tpt, p.ntasks, qpad, bmax,
-                       tmax, sel_tiles, meta);
+                       tmax, sel_tiles, meta, gate);
     MMR_CHECK_LAUNCH();
     hipLaunchKernelGGL((rescore_kernel<T, PER>), dim3(p.ks, Qc), dim3(FIN_THREADS), 0, st, q, gal, N, p.tile_rows, sel_tiles,
-                       cand, meta);
+                       cand, meta, gate);
     MMR_CHECK_LAUNCH();
     hipLaunchKernelGGL(rank_kernel, dim3(Qc), dim3(FIN_THREADS), 0, st, N, k, p.ks, p.tile_rows, sel_tiles, cand, meta, scale,
                        eps_rel, host_bound, dev_bound,
-                       idx, score, dot64, status, flags);
+                       idx, score, dot64, status, flags, gate, qres, gres_dev, gres_rel);
     MMR_CHECK_LAUNCH();
     return MMR_OK;
 }
@@ -1899,7 +1991,8 @@ extern "C" int mmr_gallery_norm_bound(const void *gallery, mmr_dtype dtype, int6
 static int cosine_topk_impl(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, int k,
                             float scale, float gallery_norm_bound, const float *norm_bound_dev, int32_t *idx, float *score,
                             double *dot64, int32_t *status, void *workspace, size_t workspace_bytes, void *stream,
-                            const bf16_t *split_hi = nullptr, const bf16_t *split_lo = nullptr)
+                            const bf16_t *split_hi = nullptr, const bf16_t *split_lo = nullptr,
+                            const float *split_resid_dev = nullptr)
 {
     MMR_CHECK_ARG(dtype == MMR_F32 || dtype == MMR_BF16, "mmr_cosine_topk: dtype %d", (int)dtype);
     MMR_CHECK_ARG(Q >= 0 && N >= 0, "mmr_cosine_topk: negative size Q=%d N=%lld", Q, (long long)N);
@@ -1944,33 +2037,63 @@ static int cosine_topk_impl(const void *q, const void *gallery, mmr_dtype dtype,
             if (rcn != MMR_OK) return rcn;
             dev_bound = nb;
         }
+        // MMR_SCAN_F32=exact keeps the fp32-MFMA scan (exact fma chain, 1/16 of the bf16 rate) for A/B comparisons
+        static const bool exact_f32 = getenv("MMR_SCAN_F32") && !strcmp(getenv("MMR_SCAN_F32"), "exact");
+        // MMR_SPLIT_TIERS=0: split galleries go straight to the three-product scan (A/B and tests of that tier alone)
+        static const bool tiers = !(getenv("MMR_SPLIT_TIERS") && atoi(getenv("MMR_SPLIT_TIERS")) == 0);
+        const bool split = dtype == MMR_F32 && split_hi && split_lo && !exact_f32;
+        const int32_t *gate = nullptr;
+        if (split && tiers) {
+            // First tier of the split fp32 search: the bf16 scan over the hi array alone (half the bytes, one MFMA product
+            // instead of three) with bf16-rounded queries.  Its scores are off by up to |q - qh||g| + |qh||g - gh| (~1e-3 |q||g|
+            // against the three-product scan's 1e-5), so its certificate adds exactly that -- measured per query and over the
+            // gallery, see rank_kernel -- to the margin and keeps KS_MAX candidate tiles instead of k + 6; the fp64 re-score
+            // reads the fp32 rows as always.  A query it cannot certify keeps its flag and goes through the second tier
+            // below -- the three-product scan with the tight margin -- and only then to the exhaustive path.  The second
+            // tier's launches return at once when no flag is set.
+            SearchPlan p1 = make_plan(N, E, Q, k, MMR_BF16);
+            static const int ks1 = getenv("MMR_SPLIT_KS1") ? atoi(getenv("MMR_SPLIT_KS1")) : KS_MAX;
+            if (ks1 > p1.ks && ks1 <= KS_MAX) p1.ks = ks1;
+            if (workspace_bytes < p1.total) { set_error("mmr_cosine_topk: workspace %zu < required %zu", workspace_bytes, p1.total); return MMR_ENOSPC; }
+            bf16_t *qb = (bf16_t *)(ws + p1.off_qb);
+            float *qres = (float *)(ws + p1.off_qres);
+            hipLaunchKernelGGL(queries_to_bf16_kernel, dim3((Q + 3) / 4), dim3(256), 0, st, (const float *)q, Q, E, qb, qres);
+            MMR_CHECK_LAUNCH();
+            float *bmax1 = (float *)(ws + p1.off_bmax), *tmax1 = (float *)(ws + p1.off_tmax);
+            for (int q0 = 0; q0 < Q; q0 += p1.qmax) {
+                const int Qc = (Q - q0) < p1.qmax ? (Q - q0) : p1.qmax;
+                const int qpad = (Qc + 31) / 32 * 32;
+                int rc = launch_scan_bf16(E, qb + (size_t)q0 * E, split_hi, Qc, N, p1, qpad, bmax1, tmax1, st);
+                if (rc != MMR_OK) return rc;
+                MMR_DISPATCH_PER(E, float, {
+                    rc = launch_finalize<float, PER>((const float *)q + (size_t)q0 * E, (const float *)gallery, Qc, N, k, p1, qpad,
+                                                     bmax1, tmax1, scale, eps_rel, host_bound, dev_bound, idx + (size_t)q0 * k,
+                                                     score + (size_t)q0 * k, dot64 ? dot64 + (size_t)q0 * k : nullptr,
+                                                     status ? status + q0 : nullptr, flags + q0,
+                                                     (int32_t *)(ws + p1.off_seltiles), (double *)(ws + p1.off_cand),
+                                                     (FinMeta *)(ws + p1.off_meta), st, nullptr, qres + q0, split_resid_dev,
+                                                     0x1p-8f);
+                });
+                if (rc != MMR_OK) return rc;
+            }
+            gate = flags;
+        }
         const int qmax = p.qmax;
         for (int q0 = 0; q0 < Q; q0 += qmax) {
             const int Qc = (Q - q0) < qmax ? (Q - q0) : qmax;
             const int qpad = (Qc + 31) / 32 * 32;
             const char *qc = (const char *)q + (size_t)q0 * E * esz;
+            const int32_t *gq = gate ? gate + q0 : nullptr;
             int rc;
             if (dtype == MMR_BF16) {
-                switch (E) {
-                    case 128: rc = launch_scan<128>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                    case 256: rc = launch_scan<256>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                    case 512: rc = launch_scan<512>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st); break;
-                    default: {
-                        // MMR_SCAN768=32 keeps the one-wave-per-SIMD 32x32 form for A/B comparisons
-                        static const int form = getenv("MMR_SCAN768") ? atoi(getenv("MMR_SCAN768")) : 16;
-                        rc = form == 32 ? launch_scan<768>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st)
-                                        : launch_scan16<768>((const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st);
-                    } break;
-                }
+                rc = launch_scan_bf16(E, (const bf16_t *)qc, (const bf16_t *)gallery, Qc, N, p, qpad, bmax, tmax, st);
             } else {
-                // MMR_SCAN_F32=exact keeps the fp32-MFMA scan (exact fma chain, 1/16 of the bf16 rate) for A/B comparisons
-                static const bool exact_f32 = getenv("MMR_SCAN_F32") && !strcmp(getenv("MMR_SCAN_F32"), "exact");
-                if (split_hi && split_lo && !exact_f32) {        // the caller holds the gallery's hi / lo split (mmr_gallery_split_bf16)
+                if (split) {        // the caller holds the gallery's hi / lo split (mmr_gallery_split_bf16)
                     switch (E) {
-                        case 128: rc = launch_scan_split<128>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st); break;
-                        case 256: rc = launch_scan_split<256>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st); break;
-                        case 512: rc = launch_scan_split<512>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st); break;
-                        default: rc = launch_scan_split<768>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st); break;
+                        case 128: rc = launch_scan_split<128>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st, gq); break;
+                        case 256: rc = launch_scan_split<256>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st, gq); break;
+                        case 512: rc = launch_scan_split<512>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st, gq); break;
+                        default: rc = launch_scan_split<768>((const float *)qc, split_hi, split_lo, Qc, N, p, qpad, bmax, tmax, st, gq); break;
                     }
                 } else if (exact_f32) {
                     switch (E) {
@@ -2005,7 +2128,7 @@ static int cosine_topk_impl(const void *q, const void *gallery, mmr_dtype dtype,
                     rc = launch_finalize<float, PER>((const float *)qc, (const float *)gallery, Qc, N, k, p, qpad, bmax, tmax,
                                                      scale, eps_rel, host_bound, dev_bound, o_idx, o_score, o_dot, o_status, flags + q0,
                                                      (int32_t *)(ws + p.off_seltiles), (double *)(ws + p.off_cand),
-                                                     (FinMeta *)(ws + p.off_meta), st);
+                                                     (FinMeta *)(ws + p.off_meta), st, gq);
                 });
             }
             if (rc != MMR_OK) return rc;
@@ -2061,7 +2184,8 @@ extern "C" int mmr_cosine_topk_ex(const void *q, const void *gallery, mmr_dtype 
                             dot64, status, workspace, workspace_bytes, stream);
 }
 
-extern "C" int mmr_gallery_split_bf16(const float *gallery, int64_t N, int E, void *hi, void *lo, void *stream)
+extern "C" int mmr_gallery_split_bf16(const float *gallery, int64_t N, int E, void *hi, void *lo, float *resid_bound_out,
+                                      void *stream)
 {
     MMR_CHECK_ARG(N >= 0 && E >= 8 && E % 8 == 0, "mmr_gallery_split_bf16: bad shape N=%lld E=%d", (long long)N, E);
     if (N == 0) return MMR_OK;
@@ -2072,18 +2196,26 @@ extern "C" int mmr_gallery_split_bf16(const float *gallery, int64_t N, int E, vo
     hipLaunchKernelGGL(split_gallery_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gallery, n8,
                        (bf16_t *)hi, (bf16_t *)lo);
     MMR_CHECK_LAUNCH();
+    if (resid_bound_out) {
+        MMR_CHECK_HIP(hipMemsetAsync(resid_bound_out, 0, sizeof(float), (hipStream_t)stream));
+        const int64_t want = (N + 3) / 4;
+        hipLaunchKernelGGL(split_resid_max_kernel, dim3((unsigned)(want < 4096 ? want : 4096)), dim3(256), 0, (hipStream_t)stream,
+                           gallery, (const bf16_t *)hi, N, E, (unsigned int *)resid_bound_out);
+        MMR_CHECK_LAUNCH();
+    }
     return MMR_OK;
 }
 
-extern "C" int mmr_cosine_topk_split(const void *q, const void *gallery, const void *gallery_hi, const void *gallery_lo, int Q,
-                                     int64_t N, int E, int k, float scale, float gallery_norm_bound,
-                                     const float *gallery_norm_bound_dev, int32_t *idx, float *score, double *dot64,
-                                     int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
+extern "C" int mmr_cosine_topk_split(const void *q, const void *gallery, const void *gallery_hi, const void *gallery_lo,
+                                     const float *split_resid_bound_dev, int Q, int64_t N, int E, int k, float scale,
+                                     float gallery_norm_bound, const float *gallery_norm_bound_dev, int32_t *idx, float *score,
+                                     double *dot64, int32_t *status, void *workspace, size_t workspace_bytes, void *stream)
 {
     MMR_CHECK_ARG((gallery_hi && gallery_lo) || N == 0, "mmr_cosine_topk_split: null split arrays");
     MMR_CHECK_ARG((((uintptr_t)gallery_hi | (uintptr_t)gallery_lo) & 15) == 0, "mmr_cosine_topk_split: split arrays must be 16-byte aligned");
     return cosine_topk_impl(q, gallery, MMR_F32, Q, N, E, k, scale, gallery_norm_bound, gallery_norm_bound_dev, idx, score, dot64,
-                            status, workspace, workspace_bytes, stream, (const bf16_t *)gallery_hi, (const bf16_t *)gallery_lo);
+                            status, workspace, workspace_bytes, stream, (const bf16_t *)gallery_hi, (const bf16_t *)gallery_lo,
+                            split_resid_bound_dev);
 }
 
 extern "C" int mmr_similarity(const void *q, const void *gallery, mmr_dtype dtype, int Q, int64_t N, int E, float scale,

@@ -118,8 +118,9 @@ def gallery_norm_bound(gallery: torch.Tensor) -> torch.Tensor:
 
 def _local_topk(q, g, k, scale, norm_bound, want_dot64, want_status, workspace=None, norm_bound_dev=None, split=None):
     """norm_bound: caller's bound (None / <= 0: none); norm_bound_dev: measured device scalar (None: none).
-    Neither given -> the C call measures the gallery itself.  split: (hi, lo) bf16 arrays of an fp32 gallery
-    (mmr_gallery_split_bf16) -> the scan streams those (same results)."""
+    Neither given -> the C call measures the gallery itself.  split: (hi, lo, resid_bound) of an fp32 gallery
+    (mmr_gallery_split_bf16: two bf16 arrays and the device scalar max_row |g - hi|) -> the tiered split search
+    (same results)."""
     Q, E = q.shape
     N = g.shape[0]
     dev = g.device
@@ -135,8 +136,8 @@ def _local_topk(q, g, k, scale, norm_bound, want_dot64, want_status, workspace=N
     if nb != nb or nb == float("inf"):
         raise ValueError("gallery_norm_bound must be finite")
     if split is not None and g.dtype == torch.float32:
-        _lib.check(L.mmr_cosine_topk_split(q.data_ptr(), g.data_ptr(), split[0].data_ptr(), split[1].data_ptr(), Q, N, E, k,
-                                           float(scale), nb, _lib.ptr(norm_bound_dev), idx.data_ptr(), score.data_ptr(),
+        _lib.check(L.mmr_cosine_topk_split(q.data_ptr(), g.data_ptr(), split[0].data_ptr(), split[1].data_ptr(),
+                                           _lib.ptr(split[2]), Q, N, E, k, float(scale), nb, _lib.ptr(norm_bound_dev), idx.data_ptr(), score.data_ptr(),
                                            _lib.ptr(dot64), _lib.ptr(status), workspace.data_ptr(), workspace.numel(),
                                            _lib.stream_ptr(dev)))
         return idx, score, dot64, status, workspace
@@ -222,8 +223,9 @@ class GalleryIndex:
 
     def __init__(self, gallery: torch.Tensor, norm_bound: Optional[float] = None, presplit: Optional[bool] = None):
         """``presplit`` (fp32 galleries only; default: on from 4096 rows): keep the gallery's hi / lo bf16 split next to it
-        (as many bytes again as the gallery) so that every search streams the split instead of redoing it per tile --
-        identical results, ~25 % less time at >= 64 queries."""
+        (as many bytes again as the gallery): searches then scan the bf16 ``hi`` half alone first and fall back to the
+        three-product scan over both halves only for queries that pass cannot certify -- identical results, about half the
+        time of the per-call path on galleries whose top scores are not crowded."""
         if not gallery.is_cuda:
             raise RuntimeError("GalleryIndex needs a CUDA/HIP tensor")
         if gallery.dtype not in (torch.float32, torch.bfloat16):
@@ -244,10 +246,11 @@ class GalleryIndex:
         g = self.gallery
         if self._split is None:
             self._split = (torch.empty(g.shape, dtype=torch.bfloat16, device=g.device),
-                           torch.empty(g.shape, dtype=torch.bfloat16, device=g.device))
+                           torch.empty(g.shape, dtype=torch.bfloat16, device=g.device),
+                           torch.zeros(1, dtype=torch.float32, device=g.device))       # max_row |g - hi|, same scalar for life
         L = _lib.lib()
         _lib.check(L.mmr_gallery_split_bf16(g.data_ptr(), g.shape[0], g.shape[1], self._split[0].data_ptr(),
-                                            self._split[1].data_ptr(), _lib.stream_ptr(g.device)))
+                                            self._split[1].data_ptr(), self._split[2].data_ptr(), _lib.stream_ptr(g.device)))
 
     @property
     def num_rows(self) -> int:

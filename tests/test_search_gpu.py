@@ -485,3 +485,55 @@ def test_fp32_index_with_presplit_gallery_is_identical(S, oracle, device, E):
     assert torch.equal(split.search_packed(qd[:5], 10, 1.0, 1000)[..., 0] - 1000, i2[:5])
     # bf16 galleries never carry a split
     assert search.GalleryIndex(gd.bfloat16(), presplit=True)._split is None
+
+
+@pytest.mark.gpu
+def test_fp32_split_search_second_tier_certifies_what_the_bf16_tier_cannot(S, oracle, device):
+    """The split fp32 index scans the hi array alone first (bf16 operands: the certificate's margin grows by the measured
+    rounding residuals, ~3.6e-3 |q||g| here, and 32 candidate tiles are kept) and re-runs only the queries that tier leaves open
+    through the three-product scan (margin 8e-5 |q||g|, k + 6 = 16 candidate tiles) before anything reaches the exhaustive
+    path.  Query 0 has 40 near neighbours in 40 different tiles whose scores step down by 3e-5: all 40 tiles sit within the
+    first tier's margin of the 10th score (not certifiable with 32 candidates), only 3 within the second tier's.  Query 1 has
+    41 exact duplicates (no scan can certify it: exhaustive path).  All results equal the oracle and the per-call path."""
+    from mmr_amd import search
+    N, E = 50003, 512
+    gal = synth.synth_unit_rows(N, E, seed=71)
+    q = synth.synth_unit_rows(140, E, seed=72)
+    u = q[0].double()
+    u /= u.norm()
+    rows = list(range(500, 40500, 1000))
+    w = synth.synth_unit_rows(40, E, seed=73).double()
+    w -= (w @ u).unsqueeze(1) * u
+    w /= w.norm(dim=1, keepdim=True)
+    c = 0.9 - 3e-5 * torch.arange(40, dtype=torch.float64)
+    gal[rows] = (c.unsqueeze(1) * u + (1 - c * c).sqrt().unsqueeze(1) * w).float()
+    q[0] = u.float()
+    dup = list(range(900, 41900, 1000))
+    gal[dup] = gal[77].clone()
+    q[1] = gal[77].clone()
+    gd, qd = gal.to(device), q.to(device)
+    tiered = search.GalleryIndex(gd, presplit=True)
+    assert tiered._split is not None
+    vals, idx, d64, status = tiered.search(qd, 10, 100.0, return_dot64=True, return_status=True)
+    oi, os_, od = oracle.cosine_topk(q, gal, 10, scale=100.0)
+    assert np.array_equal(idx.cpu().numpy(), oi) and np.array_equal(d64.cpu().numpy(), od)
+    assert np.array_equal(vals.cpu().numpy(), os_)
+    assert idx[0].tolist() == rows[:10]
+    assert int(status[0]) == 0                                    # certified (by the second tier), not exhaustive
+    assert int(status[1]) == 1
+    plain = search.GalleryIndex(gd, presplit=False).search(qd, 10, 100.0, return_dot64=True, return_status=True)
+    for x, y in zip((vals, idx, d64, status), plain):
+        assert torch.equal(x, y)
+    # the first tier alone could not have certified query 0: its certificate, recomputed here from its definition
+    gh, qh = gal.bfloat16().float(), q[0].bfloat16().float()
+    assert abs(tiered._split[2].item() - (gal - gh).norm(dim=1).max().item()) < 1e-6        # measured residual bound
+    margin1 = ((q[0] - qh).norm() * 1.0 + q[0].norm() * (1 + 2.0 ** -8) * tiered._split[2].item() + 8e-5).item()
+    tile_max = torch.full(((N + 31) // 32,), -1e30)
+    tile_max.scatter_reduce_(0, torch.arange(N) // 32, gh @ qh, "amax")
+    kth = float(od[0, 9])
+    assert 3e-3 < margin1 < 4.2e-3
+    assert kth < tile_max.topk(33).values[32].item() + margin1 - 1e-4       # 33rd-best tile still inside the margin
+    exact = gal.double() @ q[0].double()
+    tile16 = torch.full(((N + 15) // 16,), -1e30, dtype=torch.float64)
+    tile16.scatter_reduce_(0, torch.arange(N) // 16, exact, "amax")
+    assert kth > tile16.topk(17).values[16].item() + 8e-5 + 5e-5           # second tier: 17th-best tile well outside
