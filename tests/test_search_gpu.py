@@ -537,3 +537,40 @@ def test_fp32_split_search_second_tier_certifies_what_the_bf16_tier_cannot(S, or
     tile16 = torch.full(((N + 15) // 16,), -1e30, dtype=torch.float64)
     tile16.scatter_reduce_(0, torch.arange(N) // 16, exact, "amax")
     assert kth > tile16.topk(17).values[16].item() + 8e-5 + 5e-5           # second tier: 17th-best tile well outside
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("E", [128, 768])
+def test_fp32_split_tiers_with_open_queries_in_every_chunk(S, oracle, device, E):
+    """The two tiers walk the queries in different chunk sizes (bf16 plan: 256 / 128 queries per pass, fp32 plan: 128 / 64) and
+    share one flag array: queries that only the second tier can certify, and ones that need the exhaustive path, are planted
+    in the first, a middle and the last chunk of both walks.  Results and path status equal the per-call path and the oracle."""
+    from mmr_amd import search
+    N, Q = 30011, 300
+    gal = synth.synth_unit_rows(N, E, seed=81)
+    q = synth.synth_unit_rows(Q, E, seed=82)
+    tier2_q, exh_q = [0, 130, 299], [5, 257]
+    w = synth.synth_unit_rows(40, E, seed=83).double()
+    c = 0.9 - 3e-5 * torch.arange(40, dtype=torch.float64)
+    for j, qi in enumerate(tier2_q):                              # 40 near neighbours, 3e-5 apart, in 40 different tiles
+        u = q[qi].double()
+        u /= u.norm()
+        wj = w - (w @ u).unsqueeze(1) * u
+        wj /= wj.norm(dim=1, keepdim=True)
+        rows = list(range(100 + 37 * j, 100 + 37 * j + 40 * 700, 700))
+        gal[rows] = (c.unsqueeze(1) * u + (1 - c * c).sqrt().unsqueeze(1) * wj).float()
+        q[qi] = u.float()
+    for j, qi in enumerate(exh_q):                                # 41 exact duplicates
+        src = 50 + j
+        gal[list(range(400 + 53 * j, 400 + 53 * j + 40 * 700, 700))] = gal[src].clone()
+        q[qi] = gal[src].clone()
+    gd, qd = gal.to(device), q.to(device)
+    a = search.GalleryIndex(gd, presplit=True).search(qd, 10, 100.0, return_dot64=True, return_status=True)
+    b = search.GalleryIndex(gd, presplit=False).search(qd, 10, 100.0, return_dot64=True, return_status=True)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    oi, os_, od = oracle.cosine_topk(q, gal, 10, scale=100.0)
+    assert np.array_equal(a[1].cpu().numpy(), oi) and np.array_equal(a[2].cpu().numpy(), od)
+    assert np.array_equal(a[0].cpu().numpy(), os_)
+    st = a[3].cpu()
+    assert all(int(st[i]) == 0 for i in tier2_q) and all(int(st[i]) == 1 for i in exh_q)
