@@ -574,3 +574,46 @@ def test_fp32_split_tiers_with_open_queries_in_every_chunk(S, oracle, device, E)
     assert np.array_equal(a[0].cpu().numpy(), os_)
     st = a[3].cpu()
     assert all(int(st[i]) == 0 for i in tier2_q) and all(int(st[i]) == 1 for i in exh_q)
+
+
+@pytest.mark.gpu
+def test_tiered_fp32_search_is_graph_capturable(S, oracle, device):
+    """The tiers decide on the device (flags read by the next tier's kernels), so a GalleryIndex search over a split fp32
+    gallery captures into a hipGraph like every other call of include/mmr.h: replayed on new queries -- one that only the second
+    tier certifies, one that needs the exhaustive path, ordinary ones -- it returns what the eager call and the oracle return."""
+    from mmr_amd import search
+    N, E = 20011, 512
+    gal = synth.synth_unit_rows(N, E, seed=91)
+    qa = synth.synth_unit_rows(9, E, seed=92)
+    qb = synth.synth_unit_rows(9, E, seed=93)
+    u = qb[3].double()
+    u /= u.norm()
+    w = synth.synth_unit_rows(40, E, seed=94).double()
+    w -= (w @ u).unsqueeze(1) * u
+    w /= w.norm(dim=1, keepdim=True)
+    c = 0.9 - 3e-5 * torch.arange(40, dtype=torch.float64)
+    gal[list(range(60, 60 + 40 * 480, 480))] = (c.unsqueeze(1) * u + (1 - c * c).sqrt().unsqueeze(1) * w).float()
+    qb[3] = u.float()
+    gal[list(range(200, 200 + 40 * 480, 480))] = gal[7].clone()
+    qb[5] = gal[7].clone()
+    index = search.GalleryIndex(gal.to(device), presplit=True)
+    static_q = qa.to(device).clone()
+    side = torch.cuda.Stream(device)
+    side.wait_stream(torch.cuda.current_stream(device))
+    with torch.cuda.stream(side):
+        index.search(static_q, 10, 100.0, return_dot64=True, return_status=True)            # warm: workspace allocated
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            out = index.search(static_q, 10, 100.0, return_dot64=True, return_status=True)
+    torch.cuda.current_stream(device).wait_stream(side)
+    for q in (qb, qa, qb):
+        static_q.copy_(q.to(device))
+        graph.replay()
+        torch.cuda.synchronize(device)
+        oi, os_, od = oracle.cosine_topk(q, gal, 10, scale=100.0)
+        assert np.array_equal(out[1].cpu().numpy(), oi) and np.array_equal(out[2].cpu().numpy(), od)
+        assert np.array_equal(out[0].cpu().numpy(), os_)
+        expect = [0] * 9
+        if q is qb:
+            expect[5] = 1
+        assert out[3].cpu().tolist() == expect
