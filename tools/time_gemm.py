@@ -15,6 +15,8 @@ tot = 0.0
 for name, epi, M, N, K in shapes:
     A = (torch.randn(M, K, device=dev) * 0.5).bfloat16()
     W = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    if os.environ.get("ZEROS") == "1":       # DVFS check: same instructions on all-zero operands (MI355X_MICROARCH 'DVFS give-back' item 1)
+        A.zero_(); W.zero_()
     bias = torch.randn(N, device=dev)
     out = torch.zeros(M, N, device=dev, dtype=torch.float32 if epi >= 2 else torch.bfloat16)
     for _ in range(5):
