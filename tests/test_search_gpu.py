@@ -617,3 +617,31 @@ def test_tiered_fp32_search_is_graph_capturable(S, oracle, device):
         if q is qb:
             expect[5] = 1
         assert out[3].cpu().tolist() == expect
+
+
+@pytest.mark.gpu
+@pytest.mark.slow
+def test_full_size_fp32_gallery_tiered_index_exact(S, oracle, device):
+    """1M x 512 fp32 (the reference's feature-cache dtype at BASELINE configs[1]'s size), 128 queries, k = 10: the tiered split
+    index against the per-call three-product path on ALL queries (idx, fp64 dots, scores), size-independent properties, and the
+    CPU oracle on a sample."""
+    N, E, Q, k = 1_000_000, 512, 128, 10
+    gal = synth.synth_unit_rows(N, E, seed=3)
+    q = synth.synth_unit_rows(Q, E, seed=4)
+    gd, qd = gal.to(device), q.to(device)
+    tiered = S.GalleryIndex(gd, presplit=True)
+    vals, idx, d64, status = tiered.search(qd, k, return_dot64=True, return_status=True)
+    v2, i2, d2 = S.GalleryIndex(gd, presplit=False).search(qd, k, return_dot64=True)
+    assert torch.equal(idx, i2) and torch.equal(d64, d2) and torch.equal(vals, v2)
+    idx_c, d_c = idx.cpu(), d64.cpu()
+    assert (d_c[:, :-1] >= d_c[:, 1:]).all() and ((idx_c >= 0) & (idx_c < N)).all()
+    assert all(len(set(r.tolist())) == k for r in idx_c)
+    re = (gal[idx_c.reshape(-1)].double().reshape(Q, k, E) * q.double().unsqueeze(1)).sum(-1)
+    assert (re - d_c).abs().max() < 1e-12
+    _, i11 = tiered.search(qd[:8], k + 1)
+    assert torch.equal(i11[:, :k].cpu(), idx_c[:8])
+    sample = [0, 17, Q - 1]
+    oi, _, od = oracle.cosine_topk(q[sample], gal, k)
+    assert np.array_equal(idx_c[sample].numpy(), oi) and np.array_equal(d_c[sample].numpy(), od)
+    print("status (queries on the exhaustive path):", int(status.sum()))
+    assert int(status.sum()) == 0
