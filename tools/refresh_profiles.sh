@@ -42,5 +42,5 @@ if [ -f tools/libmmr_hip_stamps.so ]; then
   echo "=== default launch policy (persistent workgroups over a full + half tile list where chosen)" >> $O/${R}_gemm_phase_times.txt
   MMR_LIB=$PWD/tools/libmmr_hip_stamps.so python tools/gemm_phase_times.py >> $O/${R}_gemm_phase_times.txt 2>&1
 fi
-(for s in "fp32:tools/time_search_fp32.py" ; do python ${s#*:}; done; E=768 QS=1,32,128,256 python tools/time_search.py; QS=1,32,64,128,256,1024 python tools/time_search.py) > $O/${R}_search_timings.txt 2>&1
+(echo "# fp32 gallery through GalleryIndex (split kept, tiered search)"; python tools/time_search_fp32.py; echo "# same, MMR_SPLIT_TIERS=0 (three-product scan for every query)"; MMR_SPLIT_TIERS=0 NS=1000000 python tools/time_search_fp32.py; echo "# bf16 galleries: E = 768, then E = 512"; E=768 QS=1,32,128,256 python tools/time_search.py; QS=1,32,64,128,256,1024 python tools/time_search.py) > $O/${R}_search_timings.txt 2>&1
 cat $O/${R}_bench.json
