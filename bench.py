@@ -26,10 +26,14 @@ Workloads (--config; names follow SURVEY.md section 8d; per RANK, weak scaling -
         batch's encode; reported beside the serial schedule and encode-only (no search leg)
 One STEP, per rank (inputs already resident in HBM): the config's encode leg (none for cfg4), then the search leg:
 local top-10 over this rank's shard; for N > 1 ONE RCCL all-gather (all_gather_into_tensor, async) of the packed
-per-shard top-10 and an exact merge.  With N > 1 the steps are software-pipelined: step i's all-gather is in
-flight while step i+1 encodes and scans, and every step's merge completes inside the timed region.
-`value` = units of the config (images, texts or queries) all ranks processed per second through the whole step;
-the legs are reported separately from HIP events recorded on the launch stream inside the timed region.
+per-shard top-10 and an exact merge.  Steps are independent batches, and --lanes of them (default 2) are in flight at
+once: step i runs on HIP stream i % lanes with the model / index workspace of that lane (`encode_image(lane=)`,
+`search(lane=)`), so one step's 150-200-tile GEMM launches and bandwidth-bound row kernels share the chip with the
+other's (+8-10 % on every config; bit-identical results).  With N > 1 a lane's all-gather is in flight while that lane's
+next step encodes and scans.  All K steps, merges included, complete inside the timed region.
+`value` = units of the config (images, texts or queries) all ranks processed per second through the whole step.
+The legs (`encode_ms`, `search_ms`) and `one_step_in_flight` come from a second pass of the same K steps strictly one after
+another (HIP events on the launch stream): with two steps in flight a leg's events would span the other lane's kernels.
 `roofline` is for the kernel that dominates the step (the bf16 MFMA GEMM; the gallery scan for cfg4);
 `roofline_search` for the gallery scan, which at 256 resident queries is paced by HBM and MFMA alike -- both
 fractions are given.  Launch durations come from HIP event pairs around every launch in a second pass over the same
@@ -191,10 +195,11 @@ def spawn_ranks(n, argv):
 
 def build_leg(args, C, custom, dev, rank, world, use_dist, dist):
     """--config build: K steps of  uint8 [B,480,640,3] (resident) -> Pillow-exact preprocess -> ViT encode -> L2-normalise ->
-    rows of a preallocated gallery, the preprocess of batch i+1 on a side stream under the encode of batch i
-    (gallery.build_gallery_overlapped).  Timed beside it in the same process: the same K batches with the two stages back
-    to back on one stream (serial), and encode alone on already-preprocessed pixels.  The overlapped gallery must equal the
-    serial one bit for bit, and the serial one the plain per-batch preprocess_batch + encode_image."""
+    rows of a preallocated gallery (gallery.build_gallery_overlapped), in three schedules: two batches in flight on two
+    streams / model workspaces (the default), everything back to back on one stream, and the preprocess of batch i+1 on a
+    side stream under the encode of batch i.  Timed beside them in the same process: encode alone on already-preprocessed
+    pixels with one and with two batches in flight, and the preprocess alone.  Every schedule's gallery must equal the serial
+    one bit for bit, and the serial one the plain per-batch preprocess_batch + encode_image."""
     import mmr_amd
     from mmr_amd import _lib, gallery, preprocess
 
@@ -229,18 +234,28 @@ def build_leg(args, C, custom, dev, rank, world, use_dist, dist):
     gallery.build_gallery_overlapped(model, batches(Wm + 2), total=(Wm + 2) * B, overlap=True)   # warm-up (both slots)
     t_ovl, g_ovl = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal, overlap=True))
     g_ovl = g_ovl.clone()
-    gallery.build_gallery_overlapped(model, batches(2), total=2 * B, overlap=False)
-    t_ser, g_ser = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal, overlap=False))
+    gallery.build_gallery_overlapped(model, batches(2), total=2 * B, lanes=1)
+    t_ser, g_ser = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal, lanes=1))
     g_ser = g_ser.clone()
+    gallery.build_gallery_overlapped(model, batches(4), total=4 * B, lanes=2)
+    t_two, g_two = timed(lambda: gallery.build_gallery_overlapped(model, batches(K), gallery=gal, lanes=2))
+    g_two = g_two.clone()
     px = [preprocess.preprocess_batch(list(r), S, out_dtype=torch.bfloat16) for r in raws]
 
-    def enc_only():
-        for i in range(K):
-            model.encode_image(px[i & 1], normalize=True, out=gal[i * B:(i + 1) * B])
-        return gal
+    def enc_only(lanes):
+        def run():
+            with gallery._Lanes(dev, lanes) as L:
+                for i in range(K):
+                    with L.run(i) as lane:
+                        model.encode_image(px[i & 1], normalize=True, out=gal[i * B:(i + 1) * B], lane=lane)
+            return gal
+        return run
 
-    enc_only()
-    t_enc, g_enc = timed(enc_only)
+    enc_only(1)()
+    t_enc, g_enc = timed(enc_only(1))
+    g_enc = g_enc.clone()
+    enc_only(2)()
+    t_enc2, g_enc2 = timed(enc_only(2))
     pre = preprocess.UniformBatchPreprocessor(B, H, W, S, device=dev, slots=1)
 
     def pre_only():
@@ -249,20 +264,20 @@ def build_leg(args, C, custom, dev, rank, world, use_dist, dist):
 
     pre_only()
     t_pre, _ = timed(pre_only)
-    same_ovl = bool(torch.equal(g_ovl, g_ser))
-    same_ref = bool(torch.equal(g_ser[:2 * B], g_enc[:2 * B])) and bool(torch.equal(g_ser, g_enc))
+    same_ovl = bool(torch.equal(g_ovl, g_ser)) and bool(torch.equal(g_two, g_ser))
+    same_ref = bool(torch.equal(g_ser, g_enc)) and bool(torch.equal(g_enc2, g_enc))
     ok = same_ovl and same_ref and bool(torch.isfinite(g_ovl.float()).all())
     gflops, n_gemm = gemm_flops_per_forward(model.cfg.vision, B)
     # roofline of the dominant kernel (the bf16 GEMMs), launch durations from a second, instrumented pass
     _lib.prof_enable(True, max(4096, 300 * K))
-    gallery.build_gallery_overlapped(model, batches(K), gallery=gal, overlap=False)
+    gallery.build_gallery_overlapped(model, batches(K), gallery=gal, lanes=1)
     torch.cuda.synchronize(dev)
     _lib.prof_enable(False)
     prof = _lib.prof_read()
     gemm_ms, gemm_n = prof["gemm"]
     gemm_tflops = gflops * (gemm_n / n_gemm) / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
     imgs = world * K * B
-    t_best = min(t_ser, t_ovl)
+    t_best = min(t_ser, t_ovl, t_two)
     line = {
         "metric": METRIC, "value": round(imgs / t_best, 1), "unit": "images/s", "n_gpus": world, "steps": K, "warmup": Wm,
         "ms_per_step": round(t_best / K * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -273,13 +288,17 @@ def build_leg(args, C, custom, dev, rank, world, use_dist, dist):
                                 f"{'; CUSTOM ' + ' '.join(custom) if custom else ''})"),
                    "name": "build", "encode_batch_per_gpu": B, "image_hw": [H, W],
                    "parallelism": f"dp{world} (no collective)" if use_dist else "single GPU",
-                   "schedule": ("value = the faster of the two schedules measured: back to back on one stream (the library default) / "
-                                "preprocess of batch i+1 on a low-priority side stream under the encode of batch i"),
+                   "schedule": ("value = the fastest of the schedules measured: two batches in flight, each preprocess -> encode on its own "
+                                "stream and model workspace (the library default) / back to back on one stream / preprocess of "
+                                "batch i+1 on a low-priority side stream under the encode of batch i"),
                    "weights": "seeded random init (no checkpoint reachable offline)"},
         "verify": "ok" if ok else "FAILED",
-        "verify_detail": {"overlapped_equals_serial_bitwise": same_ovl, "serial_equals_preprocess_batch_then_encode_bitwise": same_ref},
+        "verify_detail": {"every_schedule_equals_serial_bitwise": same_ovl, "serial_equals_preprocess_batch_then_encode_bitwise": same_ref},
+        "build_two_lanes_images_per_s": round(imgs / t_two, 1),
         "build_overlapped_images_per_s": round(imgs / t_ovl, 1), "build_serial_images_per_s": round(imgs / t_ser, 1),
-        "encode_only_images_per_s": round(imgs / t_enc, 1), "preprocess_only_images_per_s": round(imgs / t_pre, 1),
+        "encode_only_images_per_s": round(imgs / t_enc, 1), "encode_only_two_lanes_images_per_s": round(imgs / t_enc2, 1),
+        "preprocess_only_images_per_s": round(imgs / t_pre, 1),
+        "two_lanes_over_encode_only": round(t_enc / t_two, 4), "two_lanes_over_encode_only_two_lanes": round(t_enc2 / t_two, 4),
         "overlapped_over_encode_only": round(t_enc / t_ovl, 4), "serial_over_encode_only": round(t_enc / t_ser, 4),
         "roofline": {"kernel": "bf16 MFMA GEMMs of the image tower (all epilogues)", "bound": "mfma", "achieved": round(gemm_tflops, 2),
                      "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(gemm_tflops / PEAK_BF16_TFLOPS, 4), "traffic": None,
@@ -301,6 +320,8 @@ def main():
     ap.add_argument("--queries", type=int, default=None, help="override queries per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--lanes", type=int, default=2,
+                    help="steps in flight (HIP streams with their own model / index workspaces); 1 = strictly one after another")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks from this process (implied by --gpus N > 1 without a launcher); with --gpus 1 it "
                          "rehearses the process-group / all-gather path on one GPU")
@@ -384,35 +405,53 @@ def main():
     queries = synth.synth_unit_rows(QUERIES, EMBED, seed=4).bfloat16().to(dev)   # replicated on every rank
     index = search.ShardedGalleryIndex(gal, group=None) if use_dist else search.GalleryIndex(gal)
 
-    def encode():
+    LANES = max(1, args.lanes)
+    main_stream = torch.cuda.current_stream(dev)
+    lane_streams = [torch.cuda.Stream(dev) for _ in range(LANES)] if LANES > 1 else [main_stream]
+
+    def encode(lane=0):
         if ENC == "image":
-            return model.encode_image(pixels, normalize=True)
+            return model.encode_image(pixels, normalize=True, lane=lane)
         if ENC == "text":
-            return model.encode_text(ids, normalize=True)
+            return model.encode_text(ids, normalize=True, lane=lane)
         return None
 
-    def run_steps(n, events=None):
-        """n steps; with a process group the all-gather of step i overlaps step i+1 (drained at the end)."""
-        pending = None
+    def run_steps(n, events=None, lanes=LANES):
+        """n steps, `lanes` of them in flight: step i runs on HIP stream i % lanes with the model / index workspace of the same
+        number (independent batches: the second fills the CUs the first one's 150-200-tile GEMM launches and row kernels
+        leave idle).  With a process group the all-gather of a lane's step overlaps that lane's next step (drained at the
+        end).  Every step's work, merges included, is enqueued before this returns; the caller's fence waits for it."""
+        streams = lane_streams[:lanes] if lanes > 1 else [main_stream]
+        if lanes > 1:
+            for st in streams:
+                st.wait_stream(main_stream)
+        pending = [None] * lanes
         for i in range(n):
-            ev = events[i] if events else None
-            if ev:
-                ev[0].record()
-            feats = encode()
-            if ev:
-                ev[1].record()
-            q = feats if ENC == "text" else queries
-            if use_dist:
-                nxt = index.search_async(q, TOPK, 1.0)
-                if pending is not None:
-                    pending.result()
-                pending = nxt
-            else:
-                index.search(q, TOPK, 1.0)
-            if ev:
-                ev[2].record()
-        if pending is not None:
-            pending.result()
+            lane = i % lanes
+            with torch.cuda.stream(streams[lane]):
+                ev = events[i] if events else None
+                if ev:
+                    ev[0].record()
+                feats = encode(lane)
+                if ev:
+                    ev[1].record()
+                q = feats if ENC == "text" else queries
+                if use_dist:
+                    nxt = index.search_async(q, TOPK, 1.0, lane=lane)
+                    if pending[lane] is not None:
+                        pending[lane].result()
+                    pending[lane] = nxt
+                else:
+                    index.search(q, TOPK, 1.0, lane=lane)
+                if ev:
+                    ev[2].record()
+        for lane in range(lanes):
+            if pending[lane] is not None:
+                with torch.cuda.stream(streams[lane]):
+                    pending[lane].result()
+        if lanes > 1:
+            for st in streams:
+                main_stream.wait_stream(st)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -422,27 +461,37 @@ def main():
 
     run_steps(args.warmup)
     fence()
-    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     fence()
     t0 = time.perf_counter()
-    run_steps(args.steps, events)
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+
+    # The two legs, un-overlapped: the same K steps with ONE step in flight, HIP events around encode and search on the
+    # launch stream (with several steps in flight a leg's events also span the other lanes' kernels).
+    run_steps(min(args.warmup, 2), lanes=1)
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    fence()
+    t1 = time.perf_counter()
+    run_steps(args.steps, events, lanes=1)
+    fence()
+    elapsed_one = time.perf_counter() - t1
 
     # Per-kernel durations for the roofline legs: the SAME K steps again with a HIP event pair around
     # every launch, recorded on the launch stream.  Kept out of the timed region on purpose: an event
     # pair per launch serialises the queue and costs ~15% of the step time.
     _lib.prof_enable(True, max(4096, 700 * args.steps))
-    run_steps(args.steps)
+    run_steps(args.steps, lanes=1)
     fence()
     _lib.prof_enable(False)
     prof = _lib.prof_read()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, elapsed_one], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, elapsed_one = float(t[0].item()), float(t[1].item())
     ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step_one = elapsed_one / args.steps * 1e3
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in events) / args.steps
     srch_ms = sum(e[1].elapsed_time(e[2]) for e in events) / args.steps
 
@@ -556,8 +605,13 @@ def main():
                                        f"top-k per step overlapped with the next step") if use_dist else "single GPU",
                        "launch": ("self-spawned ranks" if os.environ.get("MMR_BENCH_SPAWNED") else
                                   "torch.distributed.run" if use_dist else "single process"),
+                       "steps_in_flight": LANES,
                        "weights": "seeded random init (no checkpoint reachable offline)"},
             "verify": verify, "verify_detail": verify_detail,
+            # the same K steps strictly one after another (second pass, same process): what `--lanes 1` measures; the legs
+            # below (encode_ms, search_ms and the rates derived from them) are from THAT pass
+            "one_step_in_flight": {"ms_per_step": round(ms_per_step_one, 4),
+                                   "value": round(per_step_units / (ms_per_step_one * 1e-3), 1)},
             "search_fallback_queries": fallback,
             "encode_ms": round(enc_ms, 4), "search_ms": round(srch_ms, 4),
             "search_queries_per_s": round(QUERIES / (srch_ms * 1e-3), 1),

@@ -117,7 +117,7 @@ class _Tower:
         _lib.check(self.L.mmr_tower_create(ctypes.byref(self.c), self.blob.data_ptr(), self.blob.numel(),
                                            ctypes.byref(handle)))
         self.handle = handle
-        self._ws = None
+        self._lanes = {}           # lane -> workspace tensor; lane 0 is the default (`_ws` reads it)
 
     def __del__(self):
         h, self.handle = getattr(self, "handle", None), None
@@ -127,19 +127,29 @@ class _Tower:
             except Exception:
                 pass
 
-    def workspace(self, batch: int) -> torch.Tensor:
-        need = self.L.mmr_tower_workspace_bytes(self.handle, batch)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self._ws
+    @property
+    def _ws(self):
+        return self._lanes.get(0)
 
-    def status_word(self) -> int:
+    def workspace(self, batch: int, lane: int = 0) -> torch.Tensor:
+        """The caller-owned scratch of one forward pass (include/mmr.h).  The tower object itself is read-only during a
+        forward, so calls that use DIFFERENT lanes may be in flight at once on different HIP streams (two batches of a
+        gallery build: the second fills the CUs the first one's 150-200-tile GEMM launches leave idle)."""
+        need = self.L.mmr_tower_workspace_bytes(self.handle, batch)
+        ws = self._lanes.get(lane)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self._lanes[lane] = ws
+        return ws
+
+    def status_word(self, lane: int = 0) -> int:
         """The forward pass's status word (include/mmr.h: first int32 of the workspace; bit 0 = a token id was out of
         range and clamped).  Reading it synchronises."""
-        return 0 if self._ws is None else int(self._ws[:4].view(torch.int32)[0])
+        ws = self._lanes.get(lane)
+        return 0 if ws is None else int(ws[:4].view(torch.int32)[0])
 
     def forward(self, inp: torch.Tensor, out_dtype: torch.dtype, normalize: bool, tap_after: int = -1,
-                tap: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                tap: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, lane: int = 0) -> torch.Tensor:
         B = inp.shape[0]
         if out is None:
             out = torch.empty(B, self.cfg.embed_dim, dtype=out_dtype, device=self.device)
@@ -148,7 +158,7 @@ class _Tower:
             raise ValueError(f"out must be a contiguous {out_dtype} [{B},{self.cfg.embed_dim}] tensor on {self.device}")
         if B == 0:
             return out
-        ws = self.workspace(B)
+        ws = self.workspace(B, lane)
         if inp.data_ptr() & 15:            # a slice of a larger batch can start off the 16-byte grid the kernels load on
             inp = inp.clone()
         in_code = _lib.dtype_code(inp.dtype) if self.cfg.kind == "vision" else _lib.MMR_F32
@@ -253,15 +263,18 @@ class CLIP:
         return image.to(self.device).contiguous()
 
     @torch.no_grad()
-    def encode_image(self, image: torch.Tensor, normalize: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def encode_image(self, image: torch.Tensor, normalize: bool = False, out: Optional[torch.Tensor] = None,
+                     lane: int = 0) -> torch.Tensor:
         """[B,3,S,S] -> [B,E] in ``self.dtype``; a fresh, writable tensor (callers do ``/=`` on it).  ``out``: write the
-        rows into this preallocated [B,E] tensor instead (a slice of a gallery being built) and return it."""
+        rows into this preallocated [B,E] tensor instead (a slice of a gallery being built) and return it.  ``lane``: which
+        of the model's independent workspaces the call uses -- calls on different lanes may run concurrently on different
+        HIP streams (``gallery.encode_gallery(..., lanes=2)``); calls on one lane must be stream-ordered."""
         px = self._prep_pixels(image)
         if out is not None and tuple(out.shape) != (px.shape[0], self.cfg.embed_dim):
             raise ValueError(f"out must be [{px.shape[0]},{self.cfg.embed_dim}], got {tuple(out.shape)}")
         with torch.cuda.device(self.device):
             outs = [self.visual.forward(px[s:s + self.max_batch], self._dtype, normalize,
-                                        out=None if out is None else out[s:s + self.max_batch])
+                                        out=None if out is None else out[s:s + self.max_batch], lane=lane)
                     for s in range(0, px.shape[0], self.max_batch)]
         if out is not None:
             return out
@@ -286,15 +299,15 @@ class CLIP:
             raise IndexError(f"token id outside [0,{self.cfg.text.vocab})")
         return text.to(device=self.device, dtype=torch.int32).contiguous()
 
-    def text_id_errors(self) -> bool:
-        """True if the LAST encode_text call -- all of its slices when N > max_batch -- saw a token id outside [0, vocab)
-        (the kernel clamped it).
+    def text_id_errors(self, lane: int = 0) -> bool:
+        """True if the LAST encode_text call on this lane -- all of its slices when N > max_batch -- saw a token id outside
+        [0, vocab) (the kernel clamped it).
         Synchronises the device; meant for callers that feed ids produced on the GPU."""
-        return self.text.status_word() != 0
+        return self.text.status_word(lane) != 0
 
     @torch.no_grad()
-    def encode_text(self, text: torch.Tensor, normalize: bool = False) -> torch.Tensor:
-        """int [N,77] -> [N,E]; pooled at the EOT token = ``text.argmax(-1)``."""
+    def encode_text(self, text: torch.Tensor, normalize: bool = False, lane: int = 0) -> torch.Tensor:
+        """int [N,77] -> [N,E]; pooled at the EOT token = ``text.argmax(-1)``.  ``lane``: see ``encode_image``."""
         ids = self._prep_ids(text)
         with torch.cuda.device(self.device):
             starts = range(0, ids.shape[0], self.max_batch)
@@ -304,11 +317,11 @@ class CLIP:
             acc = torch.zeros(1, dtype=torch.int32, device=self.device) if len(starts) > 1 else None
             outs = []
             for s in starts:
-                outs.append(self.text.forward(ids[s:s + self.max_batch], self._dtype, normalize))
+                outs.append(self.text.forward(ids[s:s + self.max_batch], self._dtype, normalize, lane=lane))
                 if acc is not None:
-                    acc |= self.text._ws[:4].view(torch.int32)
+                    acc |= self.text._lanes[lane][:4].view(torch.int32)
             if acc is not None:
-                self.text._ws[:4].view(torch.int32).copy_(acc)
+                self.text._lanes[lane][:4].view(torch.int32).copy_(acc)
         return outs[0] if len(outs) == 1 else torch.cat(outs) if outs else \
             torch.empty(0, self.cfg.embed_dim, dtype=self._dtype, device=self.device)
 

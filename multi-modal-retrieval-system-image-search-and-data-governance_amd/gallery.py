@@ -9,6 +9,7 @@ Here the loop body is one batched ``encode_image`` per <= batch_size images; fea
 GPU (bf16 by default, the search kernel's gallery dtype) and are only copied to the host when a
 cache file in the reference's format is asked for.
 """
+import contextlib
 import os
 import pickle
 from typing import Callable, Iterable, List, Optional, Sequence, Tuple
@@ -26,28 +27,75 @@ def _images_of(batch):
     raise TypeError(f"cannot find an image tensor in a batch of type {type(batch)}")
 
 
+class _Lanes:
+    """``n`` HIP streams for work items that are independent of each other (gallery batches): item i runs on stream i % n
+    with the model / index lane of the same number.  Entering the context makes the lane streams wait for what the caller's
+    stream holds; leaving it makes the caller's stream wait for them.  n = 1 is the caller's stream itself."""
+
+    def __init__(self, device, n: int):
+        self.n = max(1, int(n))
+        self.main = torch.cuda.current_stream(device)
+        self.streams = [self.main] if self.n == 1 else [torch.cuda.Stream(device) for _ in range(self.n)]
+
+    def __enter__(self):
+        if self.n > 1:
+            for st in self.streams:
+                st.wait_stream(self.main)
+        return self
+
+    def __exit__(self, *exc):
+        if self.n > 1:
+            for st in self.streams:
+                self.main.wait_stream(st)
+        return False
+
+    @contextlib.contextmanager
+    def run(self, i: int, *inputs: torch.Tensor):
+        """Stream context of work item i; yields its lane number.  The lane's stream first waits for what the caller's
+        stream holds NOW (a batch a generator produced there a moment ago), and ``inputs`` are marked as in use on it so the
+        caching allocator does not hand their memory out while the lane still reads them."""
+        k = i % self.n
+        st = self.streams[k]
+        if self.n > 1:
+            st.wait_stream(self.main)
+            for t in inputs:
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(st)
+        with torch.cuda.stream(st):
+            yield k
+
+
 @torch.no_grad()
 def encode_gallery(model, batches: Iterable, normalize: bool = True, out_dtype: torch.dtype = torch.bfloat16,
-                   return_labels: bool = False):
+                   return_labels: bool = False, lanes: int = 2):
     """Encode every batch of ``batches`` -> device tensor [N,E] (rows in arrival order).
 
     ``model`` is a ``mmr_amd.CLIP``; each batch is a float tensor [b,3,S,S] (or a DataLoader tuple whose
     first item is one).  ``normalize`` fuses the reference's ``f /= f.norm(dim=-1, keepdim=True)``
     into the encoder's last kernel.  Host batches are uploaded with non-blocking copies so the upload
     of batch i+1 overlaps the encode of batch i when the loader yields pinned memory.
+
+    ``lanes`` batches are in flight at once, each on its own HIP stream and model workspace (``encode_image(lane=)``):
+    a forward at batch 256 is mostly GEMM launches of 150-200 tiles on 256 CUs followed by bandwidth-bound row kernels, and
+    a second, independent forward fills what the first leaves idle -- measured +9.7 % images/s on ViT-B/32 at batch 256
+    (2.97 -> 2.70 ms per forward; a third lane adds nothing), bit-identical rows.  ``lanes=1`` is the plain loop.
     """
     prev_dtype = model.dtype
     model.to(out_dtype)
     feats: List[torch.Tensor] = []
     labels: List[torch.Tensor] = []
     try:
-        for batch in batches:
-            images, lab = _images_of(batch)
-            if images.numel() == 0:
-                continue
-            feats.append(model.encode_image(images.to(model.device, non_blocking=True), normalize=normalize))
-            if lab is not None:
-                labels.append(torch.as_tensor(lab))
+        with _Lanes(model.device, lanes) as L:
+            i = 0
+            for batch in batches:
+                images, lab = _images_of(batch)
+                if images.numel() == 0:
+                    continue
+                with L.run(i, images) as lane:
+                    feats.append(model.encode_image(images.to(model.device, non_blocking=True), normalize=normalize, lane=lane))
+                if lab is not None:
+                    labels.append(torch.as_tensor(lab))
+                i += 1
     finally:
         model.to(prev_dtype)
     out = torch.cat(feats) if feats else torch.empty(0, model.cfg.embed_dim, dtype=out_dtype, device=model.device)
@@ -75,19 +123,22 @@ def _lowest_stream_priority() -> int:
 @torch.no_grad()
 def build_gallery_overlapped(model, raw_batches: Iterable[torch.Tensor], total: Optional[int] = None,
                              out_dtype: torch.dtype = torch.bfloat16, overlap: bool = False,
-                             gallery: Optional[torch.Tensor] = None) -> torch.Tensor:
+                             gallery: Optional[torch.Tensor] = None, lanes: int = 2) -> torch.Tensor:
     """The reference's gallery loop ``preprocess -> encode_image -> normalise -> keep the row``
     (code/search_image.py:153-158) over batches of raw uint8 images [b,H,W,3] that already sit on the GPU: Pillow-exact
     bicubic resize + crop + normalise (csrc/preprocess.hip), the towers, and the L2-normalised rows written directly into a
     preallocated gallery [N,E] (``normalize=1`` fused into the encoder's last kernel; no torch.cat, no host round trip).
 
-    Two schedules, bit-identical results (tested):
-      * ``overlap=False`` (default): both stages back to back on the caller's stream.  Measured on MI355X (ViT-B/32, 256 VGA
-        images per batch): 0.936 of the encode-only rate -- the preprocess costs 0.15 ms of the 3.1 ms step.
-      * ``overlap=True``: batch i+1 is preprocessed on a low-priority side stream while batch i is encoded.  Measured SLOWER
-        (0.77 of encode-only, whatever the stream priority): the encoder's GEMMs are one 160 KiB-LDS workgroup per CU, and a
-        CU that holds preprocess workgroups cannot take one, so the persistent tile schedules start ragged.  Kept because it
-        is the schedule to use with an encoder that leaves CUs free (small batches).
+    Schedules, bit-identical results (tested):
+      * ``lanes=2`` (default): two batches in flight, each preprocess -> encode on its own HIP stream with its own pixel
+        buffer and model workspace (``encode_image(lane=)``); the second batch fills the CUs the first one's 150-200-tile
+        GEMM launches and row kernels leave idle.  ``lanes=1``: everything back to back on the caller's stream (measured on
+        MI355X, ViT-B/32, 256 VGA images per batch: 0.94 of the one-lane encode-only rate -- the preprocess costs 0.15 ms of
+        the 3.1 ms step).
+      * ``overlap=True`` (one lane): batch i+1 is preprocessed on a low-priority side stream while batch i is encoded.
+        Measured SLOWER (0.77 of encode-only, whatever the stream priority): the encoder's GEMMs are one 160 KiB-LDS
+        workgroup per CU, and a CU that holds preprocess workgroups cannot take one, so the persistent tile schedules start
+        ragged.  Kept because it is the schedule to use with an encoder that leaves CUs free (small batches).
     All batches must share one image size (``UniformBatchPreprocessor``).  Returns the gallery (rows in arrival order)."""
     from .preprocess import UniformBatchPreprocessor
 
@@ -106,7 +157,24 @@ def build_gallery_overlapped(model, raw_batches: Iterable[torch.Tensor], total: 
     prev_dtype = model.dtype
     model.to(gallery.dtype)
     S = model.input_resolution
-    pre = UniformBatchPreprocessor(B, H, W, S, out_dtype=torch.bfloat16, device=dev, slots=2)
+    lanes = 1 if overlap else max(1, int(lanes))
+    pre = UniformBatchPreprocessor(B, H, W, S, out_dtype=torch.bfloat16, device=dev, slots=max(2, lanes))
+    if lanes > 1:
+        row = 0
+        try:
+            with _Lanes(dev, lanes) as L:
+                cur, i = first, 0
+                while cur is not None:
+                    b = int(cur.shape[0])
+                    if row + b > gallery.shape[0]:
+                        raise ValueError(f"gallery of {gallery.shape[0]} rows is too small")
+                    with L.run(i, cur) as lane:
+                        model.encode_image(pre(cur, lane), normalize=True, out=gallery[row:row + b], lane=lane)
+                    row += b
+                    cur, i = next(it, None), i + 1
+        finally:
+            model.to(prev_dtype)
+        return gallery[:row]
     main = torch.cuda.current_stream(dev)
     # the preprocess stream runs at the LOWEST priority the device offers: its short workgroups (8 image rows each) fill
     # CUs the encoder's launches leave idle, and the encoder's one-workgroup-per-CU GEMMs are dispatched ahead of them

@@ -227,8 +227,16 @@ class UniformBatchPreprocessor:
             raise ValueError(f"batch {b} outside [1,{self.B}]")
         images_u8 = images_u8.contiguous()
         sl = self.slots[slot]
-        sl["desc_h"].numpy()[:b, 0] = images_u8.data_ptr() + np.arange(b, dtype=np.int64) * (self.H * self.W * 3)
-        sl["desc_d"][:b].copy_(sl["desc_h"][:b], non_blocking=True)
+        key = (images_u8.data_ptr(), b)
+        if sl.get("key") != key:               # same buffer as last time (a staging ring): the device descriptors still hold
+            ev = sl.get("copied")
+            if ev is not None:
+                ev.synchronize()               # the previous upload FROM this pinned block must have left before it is rewritten
+            sl["desc_h"].numpy()[:b, 0] = images_u8.data_ptr() + np.arange(b, dtype=np.int64) * (self.H * self.W * 3)
+            sl["desc_d"][:b].copy_(sl["desc_h"][:b], non_blocking=True)
+            sl["copied"] = torch.cuda.Event()
+            sl["copied"].record()
+            sl["key"] = key
         out = sl["out"][:b]
         L = _lib.lib()
         _lib.check(L.mmr_preprocess_batch_ex(sl["desc_d"].data_ptr(), b, self.S, int(self.rows), self.W, float(self.mean[0]),

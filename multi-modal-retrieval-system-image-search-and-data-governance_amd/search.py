@@ -233,7 +233,7 @@ class GalleryIndex:
         self.gallery = gallery.contiguous()
         self.norm_bound = None if norm_bound is None else float(norm_bound)
         self.norm_bound_dev = gallery_norm_bound(self.gallery)
-        self._ws = None
+        self._ws_lanes = {}        # lane -> search workspace: searches on different lanes may overlap on different streams
         self._split = None
         if presplit is None:
             presplit = self.gallery.shape[0] >= 4096
@@ -271,12 +271,14 @@ class GalleryIndex:
         self.refresh_norm_bound()
 
     def search(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0, return_dot64: bool = False,
-               return_status: bool = False):
+               return_status: bool = False, lane: int = 0):
+        """``lane``: which of the index's workspaces the call uses; searches on different lanes may be in flight at once on
+        different HIP streams (they only read the gallery), searches on one lane must be stream-ordered."""
         q2, squeezed = _as_2d(queries)
         q = q2.to(device=self.gallery.device, dtype=self.gallery.dtype).contiguous()
-        idx, score, dot64, status, self._ws = _local_topk(q, self.gallery, int(k), scale, self.norm_bound,
-                                                          return_dot64, return_status, self._ws, self.norm_bound_dev,
-                                                          self._split)
+        idx, score, dot64, status, self._ws_lanes[lane] = _local_topk(q, self.gallery, int(k), scale, self.norm_bound,
+                                                                      return_dot64, return_status, self._ws_lanes.get(lane),
+                                                                      self.norm_bound_dev, self._split)
         idx = idx.to(torch.int64)
         if squeezed:
             idx, score = idx[0], score[0]
@@ -288,12 +290,12 @@ class GalleryIndex:
             out = out + (status,)
         return out
 
-    def search_packed(self, queries2d: torch.Tensor, k: int, scale: float, row_offset: int) -> torch.Tensor:
+    def search_packed(self, queries2d: torch.Tensor, k: int, scale: float, row_offset: int, lane: int = 0) -> torch.Tensor:
         """This shard's all-gather message for [Q,E] queries: [Q,k,2] int64 = (global row id or -1, fp64 dot bits),
         written by one kernel straight from the search outputs (mmr_topk_pack)."""
         q = queries2d.to(device=self.gallery.device, dtype=self.gallery.dtype).contiguous()
-        idx, _, dot64, _, self._ws = _local_topk(q, self.gallery, int(k), scale, self.norm_bound, True, False, self._ws,
-                                                 self.norm_bound_dev, self._split)
+        idx, _, dot64, _, self._ws_lanes[lane] = _local_topk(q, self.gallery, int(k), scale, self.norm_bound, True, False,
+                                                             self._ws_lanes.get(lane), self.norm_bound_dev, self._split)
         packed = torch.empty(q.shape[0], int(k), 2, dtype=torch.int64, device=q.device)
         L = _lib.lib()
         _lib.check(L.mmr_topk_pack(idx.data_ptr(), dot64.data_ptr(), q.shape[0], int(k), int(row_offset), packed.data_ptr(),
@@ -376,11 +378,11 @@ class ShardedGalleryIndex:
         gidx = torch.where(lidx >= 0, lidx.to(torch.int64) + self.offset, lidx.to(torch.int64))
         return gidx, ldot
 
-    def search_async(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0) -> _PendingSearch:
+    def search_async(self, queries: torch.Tensor, k: int = 10, scale: float = 1.0, lane: int = 0) -> _PendingSearch:
         squeezed = queries.dim() == 1
         if self._local_search is None:
             q2, _ = _as_2d(queries)
-            packed = self._index.search_packed(q2, k, scale, self.offset)     # one kernel after the search
+            packed = self._index.search_packed(q2, k, scale, self.offset, lane)     # one kernel after the search
         else:
             gidx, ldot = self.local_topk(queries, k, scale)
             # one packed message per rank: [Q,k,2] int64 = (global id, fp64 dot bits)

@@ -692,3 +692,57 @@ def test_short_attention_many_pairs_per_workgroup_is_bitwise_the_small_launch(L,
     ref = (torch.softmax(att, dim=-1) @ v).transpose(1, 2).reshape(40 * T, d)
     err = (big[sl].float() - ref).abs().max().item()
     assert err <= 1.3e-2 * ref.abs().max().item() + 1e-4, f"T={T}: {err / ref.abs().max().item():.2e} of max"
+
+
+def test_lanes_two_forwards_and_searches_in_flight_are_bit_identical(device):
+    """Round 3: a model and an index own one workspace per LANE, so independent batches can be in flight at once on different
+    HIP streams (gallery.encode_gallery(lanes=2), bench.py --lanes): the tower object is read-only during a forward and the
+    searches only read the gallery.  Image tower, text tower (with the out-of-range-id status word per lane) and a
+    GalleryIndex, two lanes each on its own stream, against the same calls one after another; and encode_gallery with the
+    batches produced on the fly."""
+    import mmr_amd as clip
+    from mmr_amd import gallery, search
+    model, _ = clip.load("ViT-B/32", device=device, weights="synthetic")
+    model.bfloat16()
+    S, V, T = model.input_resolution, model.cfg.text.vocab, model.cfg.text.tokens
+    g = torch.Generator().manual_seed(11)
+    px = [torch.randn(40, 3, S, S, generator=g).bfloat16().to(device) for _ in range(2)]
+    ids = [synth.synth_token_ids(24, T, V, seed=s).to(device) for s in (3, 4)]
+    ids[1][5, 2] = V + 7                                          # lane 1 only: clamped by the kernel, flagged in ITS status word
+    gal = synth.synth_unit_rows(30000, model.cfg.embed_dim, seed=9).bfloat16().to(device)
+    index = search.GalleryIndex(gal)
+    ref = []
+    for k in range(2):
+        f = model.encode_image(px[k], normalize=True)
+        t = model.encode_text(ids[k], normalize=True)
+        ref.append((f, t, index.search(f, 10, 1.0), index.search(t, 10, 1.0)))
+    torch.cuda.synchronize(device)
+    streams = [torch.cuda.Stream(device) for _ in range(2)]
+    main = torch.cuda.current_stream(device)
+    for rep in range(3):
+        out = [None, None]
+        for st in streams:
+            st.wait_stream(main)
+        for step in range(6):                                     # interleaved submission: lane 0, lane 1, lane 0, ...
+            k = step & 1
+            with torch.cuda.stream(streams[k]):
+                f = model.encode_image(px[k], normalize=True, lane=k)
+                t = model.encode_text(ids[k], normalize=True, lane=k)
+                out[k] = (f, t, index.search(f, 10, 1.0, lane=k), index.search(t, 10, 1.0, lane=k))
+        for st in streams:
+            main.wait_stream(st)
+        torch.cuda.synchronize(device)
+        for k in range(2):
+            assert torch.equal(out[k][0], ref[k][0]) and torch.equal(out[k][1], ref[k][1])
+            for a, b in zip(out[k][2] + out[k][3], ref[k][2] + ref[k][3]):
+                assert torch.equal(a, b)
+    assert model.text_id_errors(lane=1) and not model.text_id_errors(lane=0)
+    # encode_gallery: batches made on the caller's stream right before use, ragged tail, 1 / 2 / 3 lanes
+    def batches():
+        for a in range(0, 40, 12):
+            yield px[0][a:a + 12] * 1.0                           # a fresh tensor each time
+    model.float()
+    one = gallery.encode_gallery(model, batches(), lanes=1)
+    for lanes in (2, 3):
+        assert torch.equal(gallery.encode_gallery(model, batches(), lanes=lanes), one)
+    assert torch.equal(one, ref[0][0])

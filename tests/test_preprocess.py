@@ -106,9 +106,17 @@ def test_overlapped_gallery_build_equals_serial_and_pillow(device):
     dev_raws = [r.to(device) for r in raws]
     total = sum(r.shape[0] for r in raws)
     ovl = gallery.build_gallery_overlapped(model, iter(dev_raws), total=total, overlap=True).clone()
-    ser = gallery.build_gallery_overlapped(model, iter(dev_raws), total=total, overlap=False).clone()
+    ser = gallery.build_gallery_overlapped(model, iter(dev_raws), total=total, overlap=False, lanes=1).clone()
     assert ovl.shape == (total, E) and ovl.dtype == torch.bfloat16
     assert torch.equal(ovl, ser)
+    # the default schedule: two (three) batches in flight on their own streams, pixel buffers and model workspaces; the
+    # batches come from a generator that makes each one on the caller's stream just before it is consumed
+    def fresh():
+        for r in raws:
+            yield r.to(device)
+    for lanes in (2, 3):
+        two = gallery.build_gallery_overlapped(model, fresh(), total=total, lanes=lanes).clone()
+        assert torch.equal(two, ser), lanes
     # reference composition: Pillow-exact pixels (oracle) rounded to bf16 -> encode_image(normalize=True) in bf16
     model.bfloat16()
     px = torch.stack([preprocess_ref.preprocess(im.numpy(), S) for r in raws for im in r]).bfloat16().to(device)
