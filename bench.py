@@ -320,8 +320,10 @@ def main():
     ap.add_argument("--queries", type=int, default=None, help="override queries per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
-    ap.add_argument("--lanes", type=int, default=2,
-                    help="steps in flight (HIP streams with their own model / index workspaces); 1 = strictly one after another")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="steps in flight (HIP streams with their own model / index workspaces); 1 = strictly one after another; "
+                         "default 2 for the configs with an encode leg, 1 for search-only cfg4 (two gallery scans at once are "
+                         "6 %% slower than one after the other)")
     ap.add_argument("--spawn", action="store_true",
                     help="start the ranks from this process (implied by --gpus N > 1 without a launcher); with --gpus 1 it "
                          "rehearses the process-group / all-gather path on one GPU")
@@ -405,7 +407,7 @@ def main():
     queries = synth.synth_unit_rows(QUERIES, EMBED, seed=4).bfloat16().to(dev)   # replicated on every rank
     index = search.ShardedGalleryIndex(gal, group=None) if use_dist else search.GalleryIndex(gal)
 
-    LANES = max(1, args.lanes)
+    LANES = max(1, args.lanes) if args.lanes is not None else (1 if ENC == "none" else 2)
     main_stream = torch.cuda.current_stream(dev)
     lane_streams = [torch.cuda.Stream(dev) for _ in range(LANES)] if LANES > 1 else [main_stream]
 
@@ -571,13 +573,19 @@ def main():
             "traffic": (traffic or {}).get("gemm_bytes_per_launch"), "traffic_source": traffic_src,
             "avg_launch_us": round(gemm_ms / gemm_n * 1e3, 2) if gemm_n else None, "launches": gemm_n,
             "algorithmic_gflop_per_launch": round(gflops / n_gemm / 1e9, 3) if n_gemm else None,
-            "measured": "HIP event pairs around each launch on the launch stream, second pass of the same K steps "
-                        "(event pairs inflate every launch: `frac` is a floor)",
-            # the same algorithmic GEMM FLOPs over the UN-instrumented encode time of the timed region (which also holds the
-            # LayerNorm / attention / row kernels): the end-to-end figure; the kernel-level truth lies between the two and is
-            # what profiles/*_kernel_stats.csv (rocprofv3) gives
+            "measured": "HIP event pairs around each launch on the launch stream, a separate pass of the same K steps with ONE "
+                        "step in flight (event pairs inflate every launch: `frac` is a floor; with two steps in flight a "
+                        "launch's duration would include the time it shares the chip with the other lane's kernels) -- the "
+                        "rocprofv3 summary that matches it is the `--lanes 1` one",
+            # the same algorithmic GEMM FLOPs over the UN-instrumented encode time of the one-step-in-flight pass (which also
+            # holds the LayerNorm / attention / row kernels): the end-to-end figure; the kernel-level truth lies between the
+            # two and is what profiles/*_kernel_stats.csv (rocprofv3) gives
             "uninstrumented_encode_tflops": round(gflops / (enc_ms * 1e-3) / 1e12, 2) if enc_ms > 0 else None,
             "uninstrumented_encode_frac": round(gflops / (enc_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) if enc_ms > 0 else None,
+            # and over the WHOLE timed step with `steps_in_flight` steps sharing the chip (search time included, its FLOPs not):
+            # the figure the +10 % of the second lane shows up in
+            "timed_step_tflops": round(gflops / (ms_per_step * 1e-3) / 1e12, 2),
+            "timed_step_frac": round(gflops / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
         }
         roof_scan = {
             "kernel": f"scan_kernel<{EMBED}>", "bound": "hbm+mfma",

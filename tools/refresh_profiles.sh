@@ -10,14 +10,20 @@ O=gpurun_out
 rm -rf $O/prof_bench $O/pmc_fetch $O/pmc_write
 timeout -k 10 300 python bench.py > $O/${R}_bench.json 2> $O/${R}_bench.err || exit 1
 echo "bench done"
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python bench.py --no-cpu-baseline --no-sweep \
+# kernel stats of the bench command with ONE step in flight (what roofline.avg_launch_us is measured on), then of the default
+# command (two steps in flight: a launch's duration includes the time it shares the chip with the other lane's kernels)
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -- python bench.py --lanes 1 --no-cpu-baseline --no-sweep \
     > $O/${R}_bench_under_rocprof.json 2> $O/prof_bench.err || exit 1
 cp $(ls $O/prof_bench/*/*kernel_stats.csv | head -1) $O/${R}_bench_kernel_stats.csv
+rm -rf $O/prof_bench2
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench2 -- python bench.py --no-cpu-baseline --no-sweep \
+    > $O/${R}_bench_lanes2_under_rocprof.json 2> $O/prof_bench2.err || exit 1
+cp $(ls $O/prof_bench2/*/*kernel_stats.csv | head -1) $O/${R}_bench_lanes2_kernel_stats.csv
 echo "kernel trace done"
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --no-cpu-baseline --no-sweep --steps 5 --warmup 2 \
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python bench.py --lanes 1 --no-cpu-baseline --no-sweep --steps 5 --warmup 2 \
     > $O/pmc_fetch.json 2> $O/pmc_fetch.err || exit 1
 echo "pmc fetch done"
-timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --no-cpu-baseline --no-sweep --steps 5 --warmup 2 \
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python bench.py --lanes 1 --no-cpu-baseline --no-sweep --steps 5 --warmup 2 \
     > $O/pmc_write.json 2> $O/pmc_write.err || exit 1
 echo "pmc write done"
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/${R}_pmc_traffic.json > $O/pmc_summary.txt
@@ -30,7 +36,7 @@ timeout -k 10 300 python bench.py --gpus 1 --spawn --steps 20 --warmup 5 > $O/${
 timeout -k 10 300 python bench.py --config build --steps 20 --warmup 3 > $O/${R}_bench_build.json 2> $O/${R}_bench_build.err || echo "bench build failed"
 echo "spawn1 + build done"
 rm -rf $O/prof_cfg5
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg5 -- python bench.py --config cfg5 --steps 5 --warmup 2 > /dev/null 2> $O/prof_cfg5.err \
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_cfg5 -- python bench.py --lanes 1 --config cfg5 --steps 5 --warmup 2 > /dev/null 2> $O/prof_cfg5.err \
     && cp $(ls $O/prof_cfg5/*/*kernel_stats.csv | head -1) $O/${R}_bench_cfg5_kernel_stats.csv
 timeout -k 10 200 python tools/time_small_batch.py > $O/${R}_small_batch_latency.json 2> $O/small_batch.err || echo "small batch failed"
 echo "small batch done"
