@@ -54,5 +54,36 @@ for B in [int(x) for x in os.environ.get("BS", "1,10,32").split(",")]:
         same = all(torch.equal(a, b) for a, b in zip(out, ref))
         row[tag] = {"eager_ms": round(eager, 4), "graph_replay_ms": round(replay, 4), "replay_equals_eager": bool(same),
                     "images_per_s_eager": round(B / eager * 1e3, 1), "images_per_s_graph": round(B / replay * 1e3, 1)}
+    # independent requests in flight: one captured forward per LANE (own workspace, own stream), L of them replayed at once.
+    # A small-batch forward is ~100 dependent launches that leave the chip nearly idle; eager launching is host-bound
+    # (~3 us per launch), a graph replay is one host call, so the lanes overlap on the GPU.
+    if B <= 10:
+        fl = {}
+        for lanes in (1, 2, 4, 8):
+            streams = [torch.cuda.Stream(dev) for _ in range(lanes)]
+            graphs, outs = [], []
+            for l in range(lanes):
+                with torch.cuda.stream(streams[l]):
+                    model.encode_image(px, normalize=True, lane=l)
+                    gg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gg, stream=streams[l]):
+                        outs.append(model.encode_image(px, normalize=True, lane=l))
+                graphs.append(gg)
+            torch.cuda.synchronize()
+
+            def burst(n=400):
+                for i in range(n):
+                    with torch.cuda.stream(streams[i % lanes]):
+                        graphs[i % lanes].replay()
+            burst(50)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            burst()
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / 400 * 1e3
+            ref1 = model.encode_image(px, normalize=True)
+            fl[str(lanes)] = {"ms_per_forward": round(ms, 4), "images_per_s": round(B / ms * 1e3, 1),
+                              "equals_eager": bool(all(torch.equal(o, ref1) for o in outs))}
+        row["encode_graphs_in_flight"] = fl
     res[f"batch_{B}"] = row
 print(json.dumps(res, indent=1))
