@@ -428,7 +428,7 @@ def main():
             for st in streams:
                 st.wait_stream(main_stream)
         pending = [None] * lanes
-        for i in range(n):
+        def step(i):
             lane = i % lanes
             with torch.cuda.stream(streams[lane]):
                 ev = events[i] if events else None
@@ -447,6 +447,10 @@ def main():
                     index.search(q, TOPK, 1.0, lane=lane)
                 if ev:
                     ev[2].record()
+
+        with model.shared_chip(lanes > 1):           # tile policy for forwards that share the chip (mmr_tower_set_shared_chip)
+            for i in range(n):
+                step(i)
         for lane in range(lanes):
             if pending[lane] is not None:
                 with torch.cuda.stream(streams[lane]):

@@ -213,7 +213,12 @@ typedef struct mmr_tower mmr_tower;
  * a gallery build: measured +10 % images/s on ViT-B/32 at batch 256, the second batch fills the CUs the first one's 150-200-tile
  * GEMM launches leave idle); calls that share a workspace must be stream-ordered.  The same holds for mmr_cosine_topk* and its
  * workspace (searches only read the gallery).  The Python shim calls such a workspace a "lane" (encode_image(lane=),
- * GalleryIndex.search(lane=)). */
+ * GalleryIndex.search(lane=)).
+ * mmr_tower_set_shared_chip(t, 1) tells the tower that its forwards will run beside other work like that: the GEMM launches
+ * then pick their tiles for efficiency per FLOP instead of for filling 256 CUs on their own (full 256x256 tiles where the
+ * solo policy takes 256x192 ones: +2.5-3 % images/s with two ViT-B/32 forwards in flight, -5 % with one).  Results do not
+ * change (same K order per output element).  Set it while no forward of this tower is being issued. */
+int mmr_tower_set_shared_chip(mmr_tower *t, int shared);
 int mmr_tower_create(const mmr_tower_cfg *cfg, const void *weights, size_t weights_bytes, mmr_tower **out);
 void mmr_tower_destroy(mmr_tower *t);
 size_t mmr_tower_workspace_bytes(const mmr_tower *t, int batch);

@@ -103,6 +103,8 @@ def lib():
         L.mmr_tower_param_span.argtypes = [cfgp, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]
         L.mmr_tower_create.restype = i32
         L.mmr_tower_create.argtypes = [cfgp, vp, sz, ctypes.POINTER(vp)]
+        L.mmr_tower_set_shared_chip.restype = i32
+        L.mmr_tower_set_shared_chip.argtypes = [vp, i32]
         L.mmr_tower_destroy.restype = None
         L.mmr_tower_destroy.argtypes = [vp]
         L.mmr_tower_workspace_bytes.restype = sz

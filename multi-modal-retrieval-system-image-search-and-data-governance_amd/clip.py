@@ -10,6 +10,7 @@ Mirrors what the reference scripts do with the third-party ``clip`` / ``transfor
 All arithmetic is in csrc/*.hip behind include/mmr.h; this file only owns tensors and handles.
 No autograd: every reference call site wraps the encoder in ``torch.no_grad()``.
 """
+import contextlib
 import ctypes
 import os
 from typing import Dict, List, Optional, Union
@@ -131,6 +132,10 @@ class _Tower:
     def _ws(self):
         return self._lanes.get(0)
 
+    def set_shared_chip(self, shared: bool) -> None:
+        """Tile-policy hint (mmr_tower_set_shared_chip): forwards of this tower will run beside other concurrent work."""
+        _lib.check(self.L.mmr_tower_set_shared_chip(self.handle, int(bool(shared))))
+
     def workspace(self, batch: int, lane: int = 0) -> torch.Tensor:
         """The caller-owned scratch of one forward pass (include/mmr.h).  The tower object itself is read-only during a
         forward, so calls that use DIFFERENT lanes may be in flight at once on different HIP streams (two batches of a
@@ -211,6 +216,19 @@ class CLIP:
     @property
     def vocab_size(self) -> int:
         return self.cfg.text.vocab
+
+    @contextlib.contextmanager
+    def shared_chip(self, shared: bool = True):
+        """``with model.shared_chip():`` around code that keeps several batches in flight on different lanes / HIP streams
+        (``gallery._Lanes`` does it): the towers' GEMMs then choose tiles for efficiency per FLOP rather than for filling the
+        chip alone.  Same results; about +3 % images/s with two ViT-B/32 forwards in flight, -5 % with one."""
+        for t in (self.visual, self.text):
+            t.set_shared_chip(shared)
+        try:
+            yield self
+        finally:
+            for t in (self.visual, self.text):
+                t.set_shared_chip(False)
 
     def eval(self):
         return self

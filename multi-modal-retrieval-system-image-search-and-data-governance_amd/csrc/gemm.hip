@@ -1163,6 +1163,15 @@ static int launch_gemm_skinny(const bf16_t *A, const bf16_t *W, int M, int N, in
     return half ? launch_gemm_skinny_m<EPI, 64>(A, W, M, N, K, bias, out, st) : launch_gemm_skinny_m<EPI, 128>(A, W, M, N, K, bias, out, st);
 }
 
+// Hint from the tower forward (mmr_tower_set_shared_chip): this launch shares the chip with other concurrent work (a second
+// batch in flight on another stream).  The tile choice below then stops trading efficiency for occupancy: with the chip to
+// itself N = 768 at M = 12800 runs as 200 tiles of 256x192 rather than 150 of 256x256 (78 % instead of 59 % of the CUs), but
+// with a second forward filling the idle CUs the full tiles win -- 12 % fewer operand bytes per FLOP (measured, two ViT-B/32
+// forwards in flight: +2.5-3 % images/s; one in flight: -5 %).  Host-side and per thread: a forward issues all its launches
+// from the calling thread.  Same K order per output element either way, so the results do not change.
+static thread_local bool g_shared_chip = false;
+void gemm_set_shared_chip_hint(bool on) { g_shared_chip = on; }
+
 // host launcher (internal): shapes are validated by the caller in tower.hip
 int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out,
                     const GemmAux &aux, hipStream_t st)
@@ -1189,7 +1198,7 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
     const long long c256 = cost(256), c192 = cost(192);
     int tile = 128;
     if (c256 > 0) tile = 256;
-    if (c192 > 0 && (c256 < 0 || c192 < c256)) tile = 192;
+    if (c192 > 0 && (c256 < 0 || (c192 < c256 && !g_shared_chip))) tile = 192;
     if (force == 128) tile = 128;
     if (force == 256 && M % BM2 == 0 && N % 256 == 0) tile = 256;
     if (force == 192 && M % BM2 == 0 && N % 192 == 0) tile = 192;
@@ -1254,7 +1263,7 @@ int launch_gemm_patch32(const bf16_t *pix, int B, int S, const bf16_t *W, int M,
     aux.pix = pix; aux.pix_size = S; aux.pix_grid = G; aux.patch_rows = B * G * G;
     ProfScope prof(MMR_PROF_GEMM, st);
     const long long c256 = t256 >= 128 ? (t256 + 255) / 256 * 256 : -1, c192 = t192 >= 128 ? (t192 + 255) / 256 * 192 : -1;
-    if (c192 > 0 && (c256 < 0 || c192 < c256)) return launch_gemm256<EPI_STORE_F32, 3, true>(nullptr, W, M, N, K, nullptr, out, aux, st);
+    if (c192 > 0 && (c256 < 0 || (c192 < c256 && !g_shared_chip))) return launch_gemm256<EPI_STORE_F32, 3, true>(nullptr, W, M, N, K, nullptr, out, aux, st);
     return launch_gemm256<EPI_STORE_F32, 4, true>(nullptr, W, M, N, K, nullptr, out, aux, st);
 }
 

@@ -17,6 +17,7 @@ enum { EPI_BIAS_BF16 = 0, EPI_BIAS_GELU_BF16 = 1, EPI_BIAS_RESID_F32 = 2, EPI_ST
 int launch_gemm(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, hipStream_t st);
 int launch_gemm_patch32(const bf16_t *pix, int B, int S, const bf16_t *W, int M, int N, float *out, hipStream_t st);
 int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int K, const float *bias, void *out, const GemmAux &aux, hipStream_t st);
+void gemm_set_shared_chip_hint(bool on);
 // vit_ops.hip
 int launch_im2col(const void *px, mmr_dtype dt, bf16_t *ap, int B, int S, int P, int G, int K, int Kpad, hipStream_t st);
 int launch_embed_vision(const float *pe, const float *cls, const float *pos, const float *lw, const float *lb, float *h, int B, int T, int d, float eps, bf16_t *xb, float2 *stats, int32_t *status, hipStream_t st);
@@ -125,6 +126,7 @@ struct mmr_tower {
     mmr_tower_cfg cfg;
     Layout lay;
     const char *w;  // device blob
+    bool shared_chip = false;   // mmr_tower_set_shared_chip: forwards run beside other concurrent work (tile policy hint)
     template <typename T> const T *g(int p) const { return reinterpret_cast<const T *>(w + lay.global[p].off); }
     template <typename T> const T *l(int p, int layer) const {
         return reinterpret_cast<const T *>(w + lay.layer0[p].off + (size_t)layer * lay.layer_stride);
@@ -213,6 +215,13 @@ WsPlan plan_ws(const mmr_tower_cfg &c, int B)
 }
 }  // namespace
 
+extern "C" int mmr_tower_set_shared_chip(mmr_tower *t, int shared)
+{
+    MMR_CHECK_ARG(t != nullptr, "mmr_tower_set_shared_chip: null tower");
+    t->shared_chip = shared != 0;
+    return MMR_OK;
+}
+
 extern "C" size_t mmr_tower_workspace_bytes(const mmr_tower *t, int batch)
 {
     if (!t || batch < 1) return 0;
@@ -237,6 +246,10 @@ extern "C" int mmr_tower_forward(mmr_tower *t, const void *input, mmr_dtype in_d
     if (workspace_bytes < p.total) { set_error("mmr_tower_forward: workspace %zu < required %zu", workspace_bytes, p.total); return MMR_ENOSPC; }
 
     hipStream_t st = (hipStream_t)stream;
+    struct SharedHint {                      // the GEMM launchers' tile policy for the launches of this call (host side, this thread)
+        explicit SharedHint(bool on) { gemm_set_shared_chip_hint(on); }
+        ~SharedHint() { gemm_set_shared_chip_hint(false); }
+    } shared_hint(t->shared_chip);
     char *ws = (char *)workspace;
     float *h = (float *)(ws + p.off_h);
     bf16_t *x = (bf16_t *)(ws + p.off_x);

@@ -32,18 +32,23 @@ class _Lanes:
     with the model / index lane of the same number.  Entering the context makes the lane streams wait for what the caller's
     stream holds; leaving it makes the caller's stream wait for them.  n = 1 is the caller's stream itself."""
 
-    def __init__(self, device, n: int):
+    def __init__(self, device, n: int, model=None):
         self.n = max(1, int(n))
         self.main = torch.cuda.current_stream(device)
         self.streams = [self.main] if self.n == 1 else [torch.cuda.Stream(device) for _ in range(self.n)]
+        self._hint = model.shared_chip() if (model is not None and self.n > 1) else None      # tile policy for a shared chip
 
     def __enter__(self):
         if self.n > 1:
             for st in self.streams:
                 st.wait_stream(self.main)
+        if self._hint is not None:
+            self._hint.__enter__()
         return self
 
     def __exit__(self, *exc):
+        if self._hint is not None:
+            self._hint.__exit__(*exc)
         if self.n > 1:
             for st in self.streams:
                 self.main.wait_stream(st)
@@ -85,7 +90,7 @@ def encode_gallery(model, batches: Iterable, normalize: bool = True, out_dtype: 
     feats: List[torch.Tensor] = []
     labels: List[torch.Tensor] = []
     try:
-        with _Lanes(model.device, lanes) as L:
+        with _Lanes(model.device, lanes, model) as L:
             i = 0
             for batch in batches:
                 images, lab = _images_of(batch)
@@ -162,7 +167,7 @@ def build_gallery_overlapped(model, raw_batches: Iterable[torch.Tensor], total: 
     if lanes > 1:
         row = 0
         try:
-            with _Lanes(dev, lanes) as L:
+            with _Lanes(dev, lanes, model) as L:
                 cur, i = first, 0
                 while cur is not None:
                     b = int(cur.shape[0])
