@@ -737,6 +737,13 @@ def test_lanes_two_forwards_and_searches_in_flight_are_bit_identical(device):
             for a, b in zip(out[k][2] + out[k][3], ref[k][2] + ref[k][3]):
                 assert torch.equal(a, b)
     assert model.text_id_errors(lane=1) and not model.text_id_errors(lane=0)
+    # the shared-chip tile hint (full 256x256 GEMM tiles where the solo policy takes 256x192 ones) changes no bit
+    big = torch.randn(256, 3, S, S, generator=g).bfloat16().to(device)
+    solo = model.encode_image(big, normalize=True)
+    with model.shared_chip():
+        assert torch.equal(model.encode_image(big, normalize=True), solo)
+        assert torch.equal(model.encode_text(ids[0], normalize=True), ref[0][1])
+    assert torch.equal(model.encode_image(big, normalize=True), solo)
     # encode_gallery: batches made on the caller's stream right before use, ragged tail, 1 / 2 / 3 lanes
     def batches():
         for a in range(0, 40, 12):
