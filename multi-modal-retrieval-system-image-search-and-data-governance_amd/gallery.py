@@ -103,6 +103,10 @@ def encode_gallery(model, batches: Iterable, normalize: bool = True, out_dtype: 
                 i += 1
     finally:
         model.to(prev_dtype)
+    if lanes > 1:
+        main = torch.cuda.current_stream(model.device)
+        for f in feats:                        # allocated on a lane's stream, read by the concatenation on the caller's
+            f.record_stream(main)
     out = torch.cat(feats) if feats else torch.empty(0, model.cfg.embed_dim, dtype=out_dtype, device=model.device)
     if return_labels:
         return out, (torch.cat(labels) if labels else None)
