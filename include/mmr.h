@@ -216,7 +216,8 @@ typedef struct mmr_tower mmr_tower;
  * GalleryIndex.search(lane=)).
  * mmr_tower_set_shared_chip(t, 1) tells the tower that its forwards will run beside other work like that: the GEMM launches
  * then pick their tiles for efficiency per FLOP instead of for filling 256 CUs on their own (full 256x256 tiles where the
- * solo policy takes 256x192 ones: +2.5-3 % images/s with two ViT-B/32 forwards in flight, -5 % with one).  Results do not
+ * solo policy takes 256x192 ones, one workgroup per tile instead of 256 persistent ones for launches of a few long rounds:
+ * +3-5 % images/s with two ViT-B/32 forwards in flight, -5 % with one).  Results do not
  * change (same K order per output element).  Set it while no forward of this tower is being issued. */
 int mmr_tower_set_shared_chip(mmr_tower *t, int shared);
 int mmr_tower_create(const mmr_tower_cfg *cfg, const void *weights, size_t weights_bytes, mmr_tower **out);

@@ -1222,7 +1222,14 @@ int launch_gemm_aux(int epi, const bf16_t *A, const bf16_t *W, int M, int N, int
     // multi-round launches with a bf16 epilogue (qkv, fc1): persistent workgroups over a full + half tile list
     // (gemm256_persist_kernel); MMR_GEMM_PERSIST=0 falls back to one workgroup per tile (A/B aid)
     static const int persist = getenv("MMR_GEMM_PERSIST") ? atoi(getenv("MMR_GEMM_PERSIST")) : 1;
-    if (persist && tile == 256 && (long long)(M / BM2) * (N / 256) > cus) {
+    // ... unless the chip is shared (mmr_tower_set_shared_chip) and the launch is only a few rounds of long tiles: 256 workgroups
+    // pinned for the whole launch keep the other batch's kernels out, and with K >= 768 the next-tile prologue the persistent
+    // schedule hides is a small share of a tile (two ViT-B/32 forwards in flight: +1 % images/s, raw-image build +2 %; the text
+    // tower's K = 512 tiles and ViT-L/14's 13-18 rounds lose 2.5 % without persistence and keep it)
+    static const int shared_nopersist = getenv("MMR_GEMM_SHARED_NOPERSIST") ? atoi(getenv("MMR_GEMM_SHARED_NOPERSIST")) : 1;   // A/B aid
+    const long long tiles256 = (long long)(M / BM2) * (N / 256);
+    const bool yield_chip = g_shared_chip && shared_nopersist && K >= 768 && tiles256 <= 3LL * cus;
+    if (persist && tile == 256 && tiles256 > cus && !yield_chip) {
         switch (epi) {
             case EPI_BIAS_BF16: return launch_gemm256_persist<EPI_BIAS_BF16>(A, W, M, N, K, bias, out, st);
             case EPI_BIAS_GELU_BF16: return launch_gemm256_persist<EPI_BIAS_GELU_BF16>(A, W, M, N, K, bias, out, st);
