@@ -465,13 +465,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    import gc
     run_steps(args.warmup)
     fence()
+    gc.collect()
+    gc.disable()                 # a collection pause in the launching thread would be charged to a 10-60 ms timed region
     fence()
     t0 = time.perf_counter()
     run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     # The two legs, un-overlapped: the same K steps with ONE step in flight, HIP events around encode and search on the
     # launch stream (with several steps in flight a leg's events also span the other lanes' kernels).
